@@ -1,0 +1,123 @@
+/*
+ * speech_hip.h -- C ABI of libspeech_hip.so: gfx950 (MI355X) kernels for the fernand/speech
+ * ASR hot path.  This is the drop-in boundary: plain pointers and sizes, no torch types.
+ *
+ * Conventions (all entry points):
+ *   - return 0 on success, a negative SP_E* code on error; sp_last_error() gives the message
+ *     of the calling thread's last failure;
+ *   - every buffer is caller-owned DEVICE memory unless a parameter says "host";
+ *   - work is enqueued on `stream` (a hipStream_t passed as void*; NULL = default stream)
+ *     and is asynchronous: no hidden synchronisation, no allocation (query *_workspace_bytes
+ *     and pass the workspace in);
+ *   - shapes are validated on the host before any launch; a shape the kernels do not
+ *     support is an error, never a silent fallback.
+ *
+ * The reference has no FFI of its own (it is pure Python over torch/torchaudio/sru wheels);
+ * each entry point below cites the reference call site whose arithmetic it replaces.
+ */
+#ifndef SPEECH_HIP_H
+#define SPEECH_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define SP_OK 0
+#define SP_EINVAL (-1)      /* bad argument / unsupported shape */
+#define SP_EWORKSPACE (-2)  /* workspace too small */
+#define SP_ELAUNCH (-3)     /* HIP launch/runtime error */
+
+/* element types of activation buffers */
+#define SP_F32 0
+#define SP_F16 1
+#define SP_BF16 2
+
+const char* sp_last_error(void);
+int sp_version(void);
+
+/* ---------------------------------------------------------------------------------------
+ * Frontend.  Replaces data.py:15-24 (torchaudio MelSpectrogram(16000, n_fft=400, hop=160,
+ * n_mels=80, power=1.0) + FrequencyMasking(15) + TimeMasking(35)) and the zero padding of
+ * data.py:174-175 (pad_sequence -> [B,1,80,Tmax]).
+ *
+ * sp_melspec_plan_bytes / sp_melspec_plan: turn a HOST filterbank [201 x 80] (row-major,
+ * fb[f*80+m], what torchaudio.functional.melscale_fbanks returns) into a device "plan"
+ * (twiddles, window, band-limited filterbank tiles).  Done once; the plan is caller-owned.
+ *
+ * sp_melspec_fwd: wav = concatenated utterances (f32, [-1,1]); wav_offsets[B+1] (DEVICE int64,
+ * in samples) delimits them.  Utterance b has N_b = off[b+1]-off[b] samples (N_b > 200,
+ * reflect padding needs it; the caller checks) and T_b = 1 + N_b/160 frames.  out is
+ * [B, 80, T_max] f32 (= [B,1,80,T_max]); frames t >= T_b are written as 0.  masks: DEVICE
+ * int32 [B][4] = (f0, fw, t0, tw) or NULL; rows [f0,f0+fw) and frames [t0,t0+tw) of utterance b
+ * become 0.  flags: bit0 = natural log of (mel + 1e-6) (not reference behaviour; 0 = parity).
+ * --------------------------------------------------------------------------------------- */
+size_t sp_melspec_plan_bytes(void);
+int sp_melspec_plan(const float* fbank_host, void* plan_dev, void* stream);
+int sp_melspec_fwd(const float* wav, const int64_t* wav_offsets, int B, int T_max,
+                   const void* plan_dev, const int32_t* masks, int flags, float* out,
+                   void* stream);
+
+/* ---------------------------------------------------------------------------------------
+ * CTC.  Replaces train.py:69-77 / :114-122: F.log_softmax(dim=2) -> transpose ->
+ * torch.nn.CTCLoss(blank=0) (reduction "mean", zero_infinity False), forward and gradient.
+ *
+ * logits: element (t,b,c) at logits[t*stride_t + b*stride_b + c] (f32), so both the model's
+ * [B,T,V] output and the reference's [T,B,V] copy can be passed without a transpose.
+ * labels int64 [B][label_stride] (padded), input_lengths/label_lengths int32 [B] (device).
+ * max_label_len: host upper bound on label_lengths (sizes the lattice; <= 1023).
+ * Outputs: nll[B] (per-utterance negative log likelihood, +inf if infeasible), loss[1] =
+ * mean_b nll_b / max(L_b,1), grad (may be NULL) laid out like logits =
+ * grad_scale * d loss / d logits; frames t >= input_lengths[b] get 0.
+ * --------------------------------------------------------------------------------------- */
+size_t sp_ctc_workspace_bytes(int T, int B, int V, int max_label_len);
+int sp_ctc_fwd_bwd(const float* logits, int64_t stride_t, int64_t stride_b, const int64_t* labels,
+                   int label_stride, const int32_t* input_lengths, const int32_t* label_lengths,
+                   int T, int B, int V, int blank, int max_label_len, float grad_scale,
+                   float* nll, float* loss, float* grad, void* workspace, size_t workspace_bytes,
+                   void* stream);
+
+/* ---------------------------------------------------------------------------------------
+ * Greedy CTC decode.  Replaces decoder.py:28-57: argmax over V (ties -> lowest index, NaN
+ * counts as maximum, as torch.argmax), drop blanks, drop a frame equal to its predecessor.
+ * scores [B][T][V] contiguous, dtype SP_F32/SP_F16/SP_BF16.  frame_lengths int32 [B] or NULL
+ * (NULL = all T frames, which is what the reference does).  ids int32 [B][T]: the decoded
+ * ids of utterance b occupy ids[b][0 .. lengths[b]), the rest is -1.
+ * --------------------------------------------------------------------------------------- */
+int sp_greedy_decode(const void* scores, int dtype, int B, int T, int V, int blank,
+                     const int32_t* frame_lengths, int32_t* ids, int32_t* lengths, void* stream);
+
+/* Host-side unit-cost edit distance on int32 sequences (what Levenshtein.distance computes
+ * for decoder.py:17 and :25).  Host pointers; returns the distance (>= 0). */
+int sp_edit_distance(const int32_t* a, int na, const int32_t* b, int nb);
+
+/* ---------------------------------------------------------------------------------------
+ * SRU recurrence.  Replaces the `sru` package's fused recurrence kernel invoked through
+ * net.py:61-72 (sru.SRU(..., bidirectional=True, layer_norm=True, rescale=False,
+ * highway_bias=0)).  One launch = one layer, both directions.
+ *
+ * Layout (internal, chosen for coalescing; the Python wrapper permutes `weight` columns):
+ *   U   [T*B][k][2][d]   gate pre-activations, k = 3 or 4 planes (u0, u1=forget, u2=reset,
+ *                        u3=highway input when k == 4); dir 0 runs t = 0..T-1, dir 1 runs
+ *                        t = T-1..0
+ *   xres [T*B][2][d]     highway input when k == 3 (the layer's un-normalised input)
+ *   wc, bias [2][2][d]   (v_f | v_r), (b_f | b_r), f32
+ *   mask [B][2][d] f32 or NULL   variational dropout mask on the cell state (already / (1-p))
+ *   h   [T*B][2][d]      output, act dtype;   c [T*B][2][d] f32 cell states (kept for backward)
+ * dtype = element type of U, xres, h, and of gh/gU/gxres in the backward.
+ * Backward: gh is d loss / d h.  Writes gU (same layout as U), gxres ([T*B][2][d], k == 3
+ * only, else may be NULL), and ACCUMULATES into gwc/gbias ([2][2][d] f32, caller zeroes).
+ * --------------------------------------------------------------------------------------- */
+int sp_sru_fwd(const void* U, const void* xres, const float* wc, const float* bias,
+               const float* mask, int T, int B, int d, int k, int dtype, void* h, float* c,
+               void* stream);
+int sp_sru_bwd(const void* U, const void* xres, const float* wc, const float* bias,
+               const float* mask, const float* c, const void* gh, int T, int B, int d, int k,
+               int dtype, void* gU, void* gxres, float* gwc, float* gbias, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* SPEECH_HIP_H */

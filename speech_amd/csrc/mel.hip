@@ -1,0 +1,234 @@
+// Fused magnitude-mel frontend for gfx950: framing (centre, reflect pad) + periodic Hann +
+// 400-point real FFT + |.| + 201x80 mel projection + SpecAugment masks + zero padding, one pass.
+// Replaces data.py:15-24 and the padding of data.py:174-175 of the reference (torchaudio
+// MelSpectrogram on CPU DataLoader workers, one utterance at a time).
+//
+// Work decomposition: one WAVE owns 8 consecutive frames of one utterance and runs the whole
+// chain for them without any workgroup barrier (4 independent waves per 256-thread block, so
+// waves drift apart and overlap each other's load / VALU / LDS phases):
+//   phase 1  200 lane-tasks (frame, n2): 16 windowed samples -> 8-point DFT -> W200 twiddle -> LDS
+//   phase 2   64 lane-tasks (frame, k1): 25-point DFT (5x5) entirely in registers -> LDS (in place)
+//   phase 3  808 lane-tasks (frame, k<=100): real-FFT split + magnitude for bins k and 200-k -> LDS
+//   phase 4  mel projection on the matrix cores: v_mfma_f32_16x16x4_f32 (exact f32), mel x frame
+//            tiles, only over the 4-bin blocks where the 16-mel tile's filters are non-zero
+//   phase 5  masked / padded store, [B][80][T_max]
+// HBM traffic: every sample is read once from HBM (the 2.5x frame overlap is served by L1/L2),
+// every output element written once.  LDS: 19.2 KB per wave, 77 KB per block, 2 blocks per CU.
+#include <cstring>
+
+#include "common.h"
+#include "mel_math.h"
+
+namespace sp {
+using namespace melmath;
+
+constexpr int kNfft = 400, kHop = 160, kBins = 201, kMels = 80;
+constexpr int kF = 8;           // frames per wave
+constexpr int kWPB = 4;         // waves per block
+constexpr int kMagStride = 201; // odd stride: conflict-free column reads
+constexpr int kTiles = kMels / 16;
+constexpr int kMaxBlk = kTiles * 51;
+
+struct MelPlan {
+    float win[kNfft];
+    cf tw200[25][8];   // W200^(n2*k1)
+    cf tw400[104];     // W400^k, k = 0..100
+    int tile_blk0[8];  // first block of tile in fbt
+    int tile_nblk[8];
+    int tile_k0[8];    // first bin of tile
+    float fbt[kMaxBlk][64];  // A operand images: lane l -> fb[k0 + 4 blk + (l>>4)][16 tile + (l&15)]
+};
+
+struct WaveLds {
+    cf yz[kF][200];
+    float mag[kF][kMagStride];
+};
+
+using f32x4 = __attribute__((ext_vector_type(4))) float;
+
+__global__ __launch_bounds__(64 * kWPB, 2) void melspec_kernel(
+    const float* __restrict__ wav, const int64_t* __restrict__ offs, int T_max,
+    const MelPlan* __restrict__ plan, const int32_t* __restrict__ masks, int flags,
+    float* __restrict__ out) {
+    __shared__ WaveLds s_lds[kWPB];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    WaveLds& L = s_lds[wave];
+    const int b = blockIdx.y;
+    const int t0 = (blockIdx.x * kWPB + wave) * kF;
+    if (t0 >= T_max) return;
+    const int64_t off = offs[b];
+    const int N = (int)(offs[b + 1] - off);
+    const int Tb = N > 0 ? 1 + N / kHop : 0;
+    const float* x = wav + off;
+    float* outb = out + (int64_t)b * kMels * T_max;
+
+    if (t0 >= Tb) {  // pure padding: zeros
+        for (int i = lane; i < kMels * kF; i += 64) {
+            const int m = i >> 3, f = i & 7;
+            if (t0 + f < T_max) outb[(int64_t)m * T_max + t0 + f] = 0.f;
+        }
+        return;
+    }
+
+    // ------------------------------------------------------------------ phase 1
+    const bool interior = (t0 * kHop - kNfft / 2 >= 0) && ((t0 + kF - 1) * kHop + kNfft / 2 <= N) &&
+                          (t0 + kF <= Tb);
+#pragma unroll 1
+    for (int p = 0; p < 4; ++p) {
+        const int task = p * 64 + lane;
+        if (task < kF * 25) {
+            const int f = task / 25, n2 = task - f * 25;
+            const int t = t0 + f;
+            cf z[8];
+            const int base = t * kHop - kNfft / 2 + 2 * n2;
+            if (interior) {
+#pragma unroll
+                for (int n1 = 0; n1 < 8; ++n1) {
+                    const int m2 = 50 * n1 + 2 * n2;
+                    const float2 w = *reinterpret_cast<const float2*>(&plan->win[m2]);
+                    z[n1] = mk(x[base + 50 * n1] * w.x, x[base + 50 * n1 + 1] * w.y);
+                }
+            } else {
+                const bool live = t < Tb;
+#pragma unroll
+                for (int n1 = 0; n1 < 8; ++n1) {
+                    const int m2 = 50 * n1 + 2 * n2;
+                    const float2 w = *reinterpret_cast<const float2*>(&plan->win[m2]);
+                    int i0 = reflect(base + 50 * n1, N), i1 = reflect(base + 50 * n1 + 1, N);
+                    i0 = min(max(i0, 0), N - 1);
+                    i1 = min(max(i1, 0), N - 1);
+                    z[n1] = live ? mk(x[i0] * w.x, x[i1] * w.y) : mk(0.f, 0.f);
+                }
+            }
+            dft8(z);
+            L.yz[f][n2] = z[0];
+#pragma unroll
+            for (int k1 = 1; k1 < 8; ++k1) L.yz[f][k1 * 25 + n2] = mul(z[k1], plan->tw200[n2][k1]);
+        }
+    }
+    __builtin_amdgcn_wave_barrier();
+
+    // ------------------------------------------------------------------ phase 2
+    {
+        const int f = lane >> 3, k1 = lane & 7;
+        cf y[25];
+#pragma unroll
+        for (int n2 = 0; n2 < 25; ++n2) y[n2] = L.yz[f][k1 * 25 + n2];
+        dft25(y);
+        __builtin_amdgcn_wave_barrier();
+#pragma unroll
+        for (int k2 = 0; k2 < 25; ++k2) L.yz[f][k1 + 8 * k2] = y[k2];
+    }
+    __builtin_amdgcn_wave_barrier();
+
+    // ------------------------------------------------------------------ phase 3
+#pragma unroll 1
+    for (int q = 0; q < 13; ++q) {
+        const int task = q * 64 + lane;
+        if (task < kF * 101) {
+            const int f = task / 101, k = task - f * 101;
+            const int km = (k == 0) ? 0 : 200 - k;
+            float mk_, mm_;
+            real_post(L.yz[f][k], L.yz[f][km], plan->tw400[k], mk_, mm_);
+            L.mag[f][k] = mk_;
+            L.mag[f][200 - k] = mm_;
+        }
+    }
+    __builtin_amdgcn_wave_barrier();
+
+    // ------------------------------------------------------------------ phases 4 + 5
+    int mf0 = 0, mfw = 0, mt0 = 0, mtw = 0;
+    if (masks) {
+        mf0 = masks[b * 4 + 0]; mfw = masks[b * 4 + 1];
+        mt0 = masks[b * 4 + 2]; mtw = masks[b * 4 + 3];
+    }
+    const int fcol = lane & 15, kq = lane >> 4;
+    const float* magrow = L.mag[fcol & 7];
+    const int t = t0 + (fcol & 7);
+    const bool tmask = (t >= Tb) || (t >= mt0 && t < mt0 + mtw);
+#pragma unroll 1
+    for (int tile = 0; tile < kTiles; ++tile) {
+        const int nblk = plan->tile_nblk[tile];
+        const int k0 = plan->tile_k0[tile];
+        const float* a_img = plan->fbt[plan->tile_blk0[tile]] + lane;
+        f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+        for (int kb = 0; kb < nblk; ++kb) {
+            const float av = a_img[kb * 64];
+            const float bv = magrow[min(k0 + 4 * kb + kq, kBins - 1)];
+            acc = __builtin_amdgcn_mfma_f32_16x16x4f32(av, bv, acc, 0, 0, 0);
+        }
+        if (fcol < kF && t < T_max) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int mel = tile * 16 + kq * 4 + r;
+                float v = acc[r];
+                if (flags & 1) v = logf(v + 1e-6f);
+                if (tmask || (mel >= mf0 && mel < mf0 + mfw)) v = 0.f;
+                outb[(int64_t)mel * T_max + t] = v;
+            }
+        }
+    }
+}
+
+}  // namespace sp
+
+extern "C" size_t sp_melspec_plan_bytes(void) { return sizeof(sp::MelPlan); }
+
+extern "C" int sp_melspec_plan(const float* fbank_host, void* plan_dev, void* stream) {
+    using namespace sp;
+    SP_CHECK_ARG(fbank_host && plan_dev, "sp_melspec_plan: null pointer");
+    static thread_local MelPlan hp;  // ~70 KB staging copy; hipMemcpyAsync from pageable memory
+                                     // completes the host read before returning
+    std::memset(&hp, 0, sizeof(hp));
+    const double two_pi = 6.283185307179586476925286766559;
+    for (int n = 0; n < kNfft; ++n) hp.win[n] = (float)(0.5 - 0.5 * std::cos(two_pi * n / kNfft));
+    for (int n2 = 0; n2 < 25; ++n2)
+        for (int k1 = 0; k1 < 8; ++k1) {
+            const double a = two_pi * (double)(n2 * k1) / 200.0;
+            hp.tw200[n2][k1] = melmath::mk((float)std::cos(a), (float)-std::sin(a));
+        }
+    for (int k = 0; k <= 100; ++k) {
+        const double a = two_pi * (double)k / 400.0;
+        hp.tw400[k] = melmath::mk((float)std::cos(a), (float)-std::sin(a));
+    }
+    int blk = 0;
+    for (int tile = 0; tile < kTiles; ++tile) {
+        int lo = kBins, hi = -1;
+        for (int f = 0; f < kBins; ++f)
+            for (int m = 16 * tile; m < 16 * tile + 16; ++m)
+                if (fbank_host[f * kMels + m] != 0.f) {
+                    lo = f < lo ? f : lo;
+                    hi = f > hi ? f : hi;
+                }
+        hp.tile_blk0[tile] = blk;
+        hp.tile_k0[tile] = hi < 0 ? 0 : lo;
+        hp.tile_nblk[tile] = hi < 0 ? 0 : (hi - lo + 4) / 4;
+        for (int kb = 0; kb < hp.tile_nblk[tile]; ++kb, ++blk)
+            for (int l = 0; l < 64; ++l) {
+                const int f = lo + 4 * kb + (l >> 4), m = 16 * tile + (l & 15);
+                hp.fbt[blk][l] = f < kBins ? fbank_host[f * kMels + m] : 0.f;
+            }
+    }
+    hipError_t e = hipMemcpyAsync(plan_dev, &hp, sizeof(hp), hipMemcpyHostToDevice,
+                                  reinterpret_cast<hipStream_t>(stream));
+    if (e != hipSuccess) return fail(SP_ELAUNCH, "sp_melspec_plan: %s", hipGetErrorString(e));
+    e = hipStreamSynchronize(reinterpret_cast<hipStream_t>(stream));  // hp is reused by the next call
+    if (e != hipSuccess) return fail(SP_ELAUNCH, "sp_melspec_plan: %s", hipGetErrorString(e));
+    return SP_OK;
+}
+
+extern "C" int sp_melspec_fwd(const float* wav, const int64_t* wav_offsets, int B, int T_max,
+                              const void* plan_dev, const int32_t* masks, int flags, float* out,
+                              void* stream) {
+    using namespace sp;
+    SP_CHECK_ARG(B >= 0 && T_max >= 0, "sp_melspec_fwd: bad shape B=%d T_max=%d", B, T_max);
+    if (B == 0 || T_max == 0) return SP_OK;
+    SP_CHECK_ARG(wav && wav_offsets && plan_dev && out, "sp_melspec_fwd: null pointer");
+    SP_CHECK_ARG(B <= 65535, "sp_melspec_fwd: B=%d exceeds grid limit", B);
+    const int per_block = kF * kWPB;
+    dim3 grid((T_max + per_block - 1) / per_block, B);
+    hipLaunchKernelGGL(melspec_kernel, grid, dim3(64 * kWPB), 0, reinterpret_cast<hipStream_t>(stream),
+                       wav, wav_offsets, T_max, reinterpret_cast<const MelPlan*>(plan_dev), masks,
+                       flags, out);
+    return check_launch("melspec_kernel");
+}

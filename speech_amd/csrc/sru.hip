@@ -1,0 +1,247 @@
+// Bidirectional SRU recurrence (forward and backward) for gfx950.
+// Replaces the `sru` package's fused recurrence kernel that net.py:61-72 of the reference runs
+// through sru.SRU(..., bidirectional=True, layer_norm=True, rescale=False, highway_bias=0).
+//
+// The recurrence is serial in time and independent per column (batch, direction, channel):
+//   f = sigmoid(u1 + v_f c' + b_f)   r = sigmoid(u2 + v_r c' + b_r)     (c' = previous cell state)
+//   c = u0 + (c' - u0) f             h = (c m - x') r + x'
+// so parallelism is B*2*d columns only (32 k at B = 32): at most one or two waves per CU.  The
+// kernels therefore spend registers, not occupancy, on latency hiding: one lane = one column,
+// one wave = 64 adjacent channels (coalesced 128/256-byte row segments), and each wave keeps two
+// register batches of UN time steps in flight (load batch n+1 while the serial chain runs over
+// batch n).  U is laid out [T*B][k][2][d] so that each gate plane is contiguous across lanes.
+#include "common.h"
+
+namespace sp {
+
+constexpr float kL2e = 1.4426950408889634f;
+
+__device__ __forceinline__ float sigmoidf_fast(float x) {
+    return __frcp_rn(1.f + exp2f(-x * kL2e));
+}
+
+template <typename T, int K, int UN>
+__global__ __launch_bounds__(64) void sru_fwd_kernel(
+    const T* __restrict__ U, const T* __restrict__ xres, const float* __restrict__ wc,
+    const float* __restrict__ bias, const float* __restrict__ mask, int Tn, int B, int d,
+    T* __restrict__ h, float* __restrict__ cst) {
+    const int D2 = 2 * d;
+    const int col = blockIdx.x * 64 + threadIdx.x;  // over [B][2][d]
+    const int b = col / D2;
+    const int cd = col - b * D2;                      // dir*d + j
+    const int dir = cd / d;
+    const float vf = wc[cd], vr = wc[D2 + cd];
+    const float bf = bias[cd], br = bias[D2 + cd];
+    const float m = mask ? mask[col] : 1.f;
+    const int64_t ustep = (int64_t)B * K * D2;        // elements between consecutive t in U
+    const int64_t hstep = (int64_t)B * D2;
+    const T* Ub = U + (int64_t)b * K * D2 + cd;
+    const T* Xb = (K == 3) ? xres + (int64_t)b * D2 + cd : nullptr;
+    T* hb = h + (int64_t)b * D2 + cd;
+    float* cb = cst + (int64_t)b * D2 + cd;
+
+    T a0[UN], a1[UN], a2[UN], a3[UN];
+    T b0[UN], b1[UN], b2[UN], b3[UN];
+
+    auto tmap = [&](int i) { return dir ? Tn - 1 - i : i; };
+    auto load = [&](T(&u0)[UN], T(&u1)[UN], T(&u2)[UN], T(&xp)[UN], int i0) {
+#pragma unroll
+        for (int s = 0; s < UN; ++s) {
+            const int i = i0 + s;
+            if (i < Tn) {
+                const int64_t t = tmap(i);
+                const T* p = Ub + t * ustep;
+                u0[s] = p[0];
+                u1[s] = p[D2];
+                u2[s] = p[2 * D2];
+                xp[s] = (K == 3) ? Xb[t * hstep] : p[3 * D2];
+            }
+        }
+    };
+    float c = 0.f;
+    auto compute = [&](T(&u0)[UN], T(&u1)[UN], T(&u2)[UN], T(&xp)[UN], int i0) {
+#pragma unroll
+        for (int s = 0; s < UN; ++s) {
+            const int i = i0 + s;
+            if (i < Tn) {
+                const int64_t t = tmap(i);
+                const float v0 = Elem<T>::f(u0[s]), v1 = Elem<T>::f(u1[s]);
+                const float v2 = Elem<T>::f(u2[s]), x = Elem<T>::f(xp[s]);
+                const float f = sigmoidf_fast(v1 + vf * c + bf);
+                const float r = sigmoidf_fast(v2 + vr * c + br);
+                c = v0 + (c - v0) * f;
+                const float hv = (c * m - x) * r + x;
+                Elem<T>::st(hb + t * hstep, hv);
+                cb[t * hstep] = c;
+            }
+        }
+    };
+
+    load(a0, a1, a2, a3, 0);
+    for (int i0 = 0; i0 < Tn; i0 += 2 * UN) {
+        load(b0, b1, b2, b3, i0 + UN);
+        compute(a0, a1, a2, a3, i0);
+        load(a0, a1, a2, a3, i0 + 2 * UN);
+        compute(b0, b1, b2, b3, i0 + UN);
+    }
+}
+
+template <typename T, int K, int UN>
+__global__ __launch_bounds__(64) void sru_bwd_kernel(
+    const T* __restrict__ U, const T* __restrict__ xres, const float* __restrict__ wc,
+    const float* __restrict__ bias, const float* __restrict__ mask, const float* __restrict__ cst,
+    const T* __restrict__ gh, int Tn, int B, int d, T* __restrict__ gU, T* __restrict__ gxres,
+    float* __restrict__ gwc, float* __restrict__ gbias) {
+    const int D2 = 2 * d;
+    const int col = blockIdx.x * 64 + threadIdx.x;
+    const int b = col / D2;
+    const int cd = col - b * D2;
+    const int dir = cd / d;
+    const float vf = wc[cd], vr = wc[D2 + cd];
+    const float bf = bias[cd], br = bias[D2 + cd];
+    const float m = mask ? mask[col] : 1.f;
+    const int64_t ustep = (int64_t)B * K * D2;
+    const int64_t hstep = (int64_t)B * D2;
+    const T* Ub = U + (int64_t)b * K * D2 + cd;
+    T* gUb = gU + (int64_t)b * K * D2 + cd;
+    const T* Xb = (K == 3) ? xres + (int64_t)b * D2 + cd : nullptr;
+    T* gXb = (K == 3) ? gxres + (int64_t)b * D2 + cd : nullptr;
+    const T* ghb = gh + (int64_t)b * D2 + cd;
+    const float* cb = cst + (int64_t)b * D2 + cd;
+
+    struct Batch {
+        T u0[UN], u1[UN], u2[UN], xp[UN], g[UN];
+        float cp[UN];
+    };
+    Batch A, Bt;
+
+    // walk the forward order backwards: i = Tn-1 .. 0, forward-time index t = tmap(i)
+    auto tmap = [&](int i) { return dir ? Tn - 1 - i : i; };
+    auto load = [&](Batch& q, int i_hi) {  // steps i_hi, i_hi-1, ..., i_hi-UN+1
+#pragma unroll
+        for (int s = 0; s < UN; ++s) {
+            const int i = i_hi - s;
+            if (i >= 0) {
+                const int64_t t = tmap(i);
+                const T* p = Ub + t * ustep;
+                q.u0[s] = p[0];
+                q.u1[s] = p[D2];
+                q.u2[s] = p[2 * D2];
+                q.xp[s] = (K == 3) ? Xb[t * hstep] : p[3 * D2];
+                q.g[s] = ghb[t * hstep];
+                q.cp[s] = (i > 0) ? cb[(int64_t)tmap(i - 1) * hstep] : 0.f;
+            }
+        }
+    };
+    float gc = 0.f, gvf = 0.f, gvr = 0.f, gbf = 0.f, gbr = 0.f;
+    auto compute = [&](Batch& q, int i_hi) {
+#pragma unroll
+        for (int s = 0; s < UN; ++s) {
+            const int i = i_hi - s;
+            if (i >= 0) {
+                const int64_t t = tmap(i);
+                const float v0 = Elem<T>::f(q.u0[s]), v1 = Elem<T>::f(q.u1[s]);
+                const float v2 = Elem<T>::f(q.u2[s]), x = Elem<T>::f(q.xp[s]);
+                const float g = Elem<T>::f(q.g[s]);
+                const float cp = q.cp[s];
+                const float f = sigmoidf_fast(v1 + vf * cp + bf);
+                const float r = sigmoidf_fast(v2 + vr * cp + br);
+                const float cc = v0 + (cp - v0) * f;
+                const float gr = g * (cc * m - x);         // d/dr
+                const float gx = g * (1.f - r);            // d/dx'
+                const float gct = gc + g * r * m;          // total d/dc_t
+                const float dr = gr * r * (1.f - r);       // d/d(pre-activation of r)
+                const float g0 = gct * (1.f - f);          // d/du0
+                const float df = gct * (cp - v0) * f * (1.f - f);
+                gc = gct * f + df * vf + dr * vr;          // d/dc_{t-1}
+                gvf += df * cp; gvr += dr * cp; gbf += df; gbr += dr;
+                T* gp = gUb + t * ustep;
+                Elem<T>::st(gp, g0);
+                Elem<T>::st(gp + D2, df);
+                Elem<T>::st(gp + 2 * D2, dr);
+                if (K == 3) Elem<T>::st(gXb + t * hstep, gx);
+                else Elem<T>::st(gp + 3 * D2, gx);
+            }
+        }
+    };
+
+    load(A, Tn - 1);
+    for (int i_hi = Tn - 1; i_hi >= 0; i_hi -= 2 * UN) {
+        load(Bt, i_hi - UN);
+        compute(A, i_hi);
+        load(A, i_hi - 2 * UN);
+        compute(Bt, i_hi - UN);
+    }
+    atomicAdd(&gwc[cd], gvf);
+    atomicAdd(&gwc[D2 + cd], gvr);
+    atomicAdd(&gbias[cd], gbf);
+    atomicAdd(&gbias[D2 + cd], gbr);
+}
+
+template <typename T>
+static int sru_fwd_t(const void* U, const void* xres, const float* wc, const float* bias,
+                     const float* mask, int Tn, int B, int d, int k, void* h, float* c, hipStream_t s) {
+    const int blocks = B * 2 * d / 64;
+    if (k == 3)
+        hipLaunchKernelGGL((sru_fwd_kernel<T, 3, 16>), dim3(blocks), dim3(64), 0, s, (const T*)U,
+                           (const T*)xres, wc, bias, mask, Tn, B, d, (T*)h, c);
+    else
+        hipLaunchKernelGGL((sru_fwd_kernel<T, 4, 16>), dim3(blocks), dim3(64), 0, s, (const T*)U,
+                           (const T*)xres, wc, bias, mask, Tn, B, d, (T*)h, c);
+    return check_launch("sru_fwd_kernel");
+}
+
+template <typename T>
+static int sru_bwd_t(const void* U, const void* xres, const float* wc, const float* bias,
+                     const float* mask, const float* c, const void* gh, int Tn, int B, int d, int k,
+                     void* gU, void* gxres, float* gwc, float* gbias, hipStream_t s) {
+    const int blocks = B * 2 * d / 64;
+    if (k == 3)
+        hipLaunchKernelGGL((sru_bwd_kernel<T, 3, 8>), dim3(blocks), dim3(64), 0, s, (const T*)U,
+                           (const T*)xres, wc, bias, mask, c, (const T*)gh, Tn, B, d, (T*)gU,
+                           (T*)gxres, gwc, gbias);
+    else
+        hipLaunchKernelGGL((sru_bwd_kernel<T, 4, 8>), dim3(blocks), dim3(64), 0, s, (const T*)U,
+                           (const T*)xres, wc, bias, mask, c, (const T*)gh, Tn, B, d, (T*)gU,
+                           (T*)gxres, gwc, gbias);
+    return check_launch("sru_bwd_kernel");
+}
+
+static int sru_check(const char* who, int Tn, int B, int d, int k, int dtype) {
+    SP_CHECK_ARG(Tn >= 0 && B >= 0 && d >= 1, "%s: bad shape T=%d B=%d d=%d", who, Tn, B, d);
+    SP_CHECK_ARG(k == 3 || k == 4, "%s: k=%d must be 3 or 4", who, k);
+    SP_CHECK_ARG(d % 64 == 0, "%s: d=%d must be a multiple of 64 (one wave = 64 channels)", who, d);
+    SP_CHECK_ARG(dtype == SP_F32 || dtype == SP_BF16, "%s: dtype %d not supported (f32, bf16)", who, dtype);
+    return SP_OK;
+}
+
+}  // namespace sp
+
+extern "C" int sp_sru_fwd(const void* U, const void* xres, const float* wc, const float* bias,
+                          const float* mask, int T, int B, int d, int k, int dtype, void* h,
+                          float* c, void* stream) {
+    using namespace sp;
+    int rc = sru_check("sp_sru_fwd", T, B, d, k, dtype);
+    if (rc) return rc;
+    if (T == 0 || B == 0) return SP_OK;
+    SP_CHECK_ARG(U && wc && bias && h && c && (k == 4 || xres), "sp_sru_fwd: null pointer");
+    hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+    if (dtype == SP_F32) return sru_fwd_t<float>(U, xres, wc, bias, mask, T, B, d, k, h, c, s);
+    return sru_fwd_t<__hip_bfloat16>(U, xres, wc, bias, mask, T, B, d, k, h, c, s);
+}
+
+extern "C" int sp_sru_bwd(const void* U, const void* xres, const float* wc, const float* bias,
+                          const float* mask, const float* c, const void* gh, int T, int B, int d,
+                          int k, int dtype, void* gU, void* gxres, float* gwc, float* gbias,
+                          void* stream) {
+    using namespace sp;
+    int rc = sru_check("sp_sru_bwd", T, B, d, k, dtype);
+    if (rc) return rc;
+    if (T == 0 || B == 0) return SP_OK;
+    SP_CHECK_ARG(U && wc && bias && c && gh && gU && gwc && gbias && (k == 4 || (xres && gxres)),
+                 "sp_sru_bwd: null pointer");
+    hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+    if (dtype == SP_F32)
+        return sru_bwd_t<float>(U, xres, wc, bias, mask, c, gh, T, B, d, k, gU, gxres, gwc, gbias, s);
+    return sru_bwd_t<__hip_bfloat16>(U, xres, wc, bias, mask, c, gh, T, B, d, k, gU, gxres, gwc, gbias, s);
+}

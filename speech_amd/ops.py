@@ -1,0 +1,267 @@
+"""Tensor-level wrappers over the C ABI (libspeech_hip.so).  torch supplies device memory and
+the current HIP stream; every computation below runs in the hand-written gfx950 kernels."""
+import ctypes
+
+import numpy as np
+import torch
+
+from . import _lib
+from ._lib import check, lib, ptr, stream_ptr
+
+HOP = 160
+N_FFT = 400
+N_MELS = 80
+N_FREQS = 201
+
+
+def _need_cuda(t, name):
+    if not t.is_cuda:
+        raise _lib.SpeechHipError(f"{name} must be a CUDA/HIP tensor (no CPU path exists)")
+
+
+# ------------------------------------------------------------------------------------------
+# Frontend (data.py:15-24, :174-175)
+# ------------------------------------------------------------------------------------------
+def melscale_fbanks_htk(n_freqs=N_FREQS, f_min=0.0, f_max=8000.0, n_mels=N_MELS, sample_rate=16000):
+    """HTK triangular filterbank [n_freqs, n_mels], norm=None -- the matrix the reference's
+    MelSpectrogram(sample_rate=16000, n_fft=400, n_mels=80) builds (data.py:16-18)."""
+    import math
+    all_freqs = torch.linspace(0, sample_rate // 2, n_freqs)
+    m_min = 2595.0 * math.log10(1.0 + f_min / 700.0)
+    m_max = 2595.0 * math.log10(1.0 + f_max / 700.0)
+    m_pts = torch.linspace(m_min, m_max, n_mels + 2)
+    f_pts = 700.0 * (10 ** (m_pts / 2595.0) - 1.0)
+    f_diff = f_pts[1:] - f_pts[:-1]
+    slopes = f_pts.unsqueeze(0) - all_freqs.unsqueeze(1)
+    down = (-1.0 * slopes[:, :-2]) / f_diff[:-1]
+    up = slopes[:, 2:] / f_diff[1:]
+    return torch.max(torch.zeros(1), torch.min(down, up))
+
+
+class MelPlan:
+    """Device-resident constants of the frontend kernel (window, twiddles, filterbank tiles)."""
+
+    def __init__(self, device, fbank=None):
+        fb = melscale_fbanks_htk() if fbank is None else fbank
+        fb = fb.detach().to("cpu", torch.float32).contiguous()
+        if tuple(fb.shape) != (N_FREQS, N_MELS):
+            raise ValueError(f"filterbank must be [{N_FREQS}, {N_MELS}], got {tuple(fb.shape)}")
+        self.device = torch.device(device)
+        nbytes = lib().sp_melspec_plan_bytes()
+        self.buf = torch.empty(nbytes, dtype=torch.uint8, device=self.device)
+        with torch.cuda.device(self.device):
+            check(lib().sp_melspec_plan(ctypes.c_void_p(fb.data_ptr()), ptr(self.buf), stream_ptr()),
+                  "sp_melspec_plan")
+
+
+_plans = {}
+
+
+def default_plan(device):
+    device = torch.device(device)
+    key = (device.type, device.index if device.index is not None else torch.cuda.current_device())
+    if key not in _plans:
+        _plans[key] = MelPlan(device)
+    return _plans[key]
+
+
+def num_frames(n_samples):
+    return 1 + n_samples // HOP
+
+
+def melspec(wav, offsets, t_max=None, masks=None, flags=0, plan=None, out=None):
+    """wav: flat f32 device tensor of concatenated utterances; offsets: int64 [B+1] (device or
+    host) -> mel [B, 1, 80, T_max] f32.  masks: int32 [B,4] (f0, fw, t0, tw) or None."""
+    _need_cuda(wav, "wav")
+    if wav.dtype != torch.float32 or not wav.is_contiguous():
+        raise ValueError("wav must be a contiguous float32 tensor")
+    offs_host = offsets.detach().cpu().to(torch.int64) if offsets.is_cuda else offsets.to(torch.int64)
+    B = offs_host.numel() - 1
+    lens = offs_host[1:] - offs_host[:-1]
+    if B > 0:
+        if int(lens.min()) <= N_FFT // 2:
+            raise ValueError("every utterance needs more than 200 samples (reflect padding)")
+        if int(offs_host[-1]) > wav.numel() or int(offs_host[0]) < 0:
+            raise ValueError("offsets exceed the waveform buffer")
+    tb_max = int(lens.max()) // HOP + 1 if B > 0 else 0
+    if t_max is None:
+        t_max = tb_max
+    if t_max < tb_max:
+        raise ValueError(f"t_max={t_max} smaller than the longest utterance ({tb_max} frames)")
+    offs_dev = offsets if offsets.is_cuda and offsets.dtype == torch.int64 else offs_host.to(wav.device)
+    if masks is not None:
+        masks = masks.to(device=wav.device, dtype=torch.int32).contiguous()
+        if tuple(masks.shape) != (B, 4):
+            raise ValueError("masks must be [B, 4]")
+    if plan is None:
+        plan = default_plan(wav.device)
+    if out is None:
+        out = torch.empty((B, 1, N_MELS, t_max), dtype=torch.float32, device=wav.device)
+    with torch.cuda.device(wav.device):
+        check(lib().sp_melspec_fwd(ptr(wav), ptr(offs_dev), B, t_max, ptr(plan.buf), ptr(masks), flags,
+                                   ptr(out), stream_ptr()), "sp_melspec_fwd")
+    return out
+
+
+# ------------------------------------------------------------------------------------------
+# CTC (train.py:69-77)
+# ------------------------------------------------------------------------------------------
+_ctc_ws = {}
+
+
+def _workspace(key, nbytes, device):
+    buf = _ctc_ws.get(key)
+    if buf is None or buf.numel() < nbytes:
+        buf = torch.empty(nbytes, dtype=torch.uint8, device=device)
+        _ctc_ws[key] = buf
+    return buf
+
+
+def ctc_fwd_bwd(logits, labels, input_lengths, label_lengths, blank=0, max_label_len=None,
+                time_major=False, grad_scale=1.0, want_grad=True):
+    """logits [B,T,V] (or [T,B,V] when time_major) f32 -> (loss[1], nll[B], grad like logits).
+
+    loss = mean_b nll_b / max(L_b, 1) of log_softmax(logits); grad = grad_scale * dloss/dlogits.
+    """
+    _need_cuda(logits, "logits")
+    if logits.dtype != torch.float32:
+        raise ValueError("logits must be float32 (the reference computes CTC in fp32)")
+    if logits.stride(2) != 1:
+        logits = logits.contiguous()
+    if time_major:
+        T, B, V = logits.shape
+        st, sb = logits.stride(0), logits.stride(1)
+    else:
+        B, T, V = logits.shape
+        sb, st = logits.stride(0), logits.stride(1)
+    dev = logits.device
+    labels = labels.to(device=dev, dtype=torch.int64)
+    if labels.dim() != 2 or labels.shape[0] != B:
+        raise ValueError("labels must be [B, Lmax]")
+    if labels.stride(1) != 1 and labels.shape[1] > 1:
+        labels = labels.contiguous()
+    if labels.numel() == 0:
+        labels = torch.zeros((B, 1), dtype=torch.int64, device=dev)
+    input_lengths = input_lengths.to(device=dev, dtype=torch.int32).contiguous()
+    label_lengths = label_lengths.to(device=dev, dtype=torch.int32).contiguous()
+    if max_label_len is None:
+        max_label_len = min(int(labels.shape[1]), 1023)
+    nll = torch.empty(B, dtype=torch.float32, device=dev)
+    loss = torch.empty(1, dtype=torch.float32, device=dev)
+    grad = torch.empty_like(logits) if want_grad else None
+    if grad is not None and grad.stride() != logits.stride():
+        grad = torch.empty_strided(logits.shape, logits.stride(), dtype=logits.dtype, device=dev)
+    nbytes = lib().sp_ctc_workspace_bytes(T, B, V, max_label_len)
+    ws = _workspace((dev.index, "ctc"), nbytes, dev)
+    with torch.cuda.device(dev):
+        check(lib().sp_ctc_fwd_bwd(ptr(logits), st, sb, ptr(labels), labels.stride(0), ptr(input_lengths),
+                                   ptr(label_lengths), T, B, V, blank, max_label_len, float(grad_scale),
+                                   ptr(nll), ptr(loss), ptr(grad), ptr(ws), ws.numel(), stream_ptr()),
+              "sp_ctc_fwd_bwd")
+    return loss, nll, grad
+
+
+class _CTCLossFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, logits, labels, input_lengths, label_lengths, blank, time_major, max_label_len):
+        loss, nll, grad = ctc_fwd_bwd(logits, labels, input_lengths, label_lengths, blank,
+                                      max_label_len, time_major, 1.0, logits.requires_grad)
+        ctx.save_for_backward(grad)
+        return loss[0]
+
+    @staticmethod
+    def backward(ctx, g):
+        (grad,) = ctx.saved_tensors
+        return grad * g, None, None, None, None, None, None
+
+
+def ctc_loss(logits, labels, input_lengths, label_lengths, blank=0, time_major=False,
+             max_label_len=None):
+    """Differentiable fused log_softmax + CTC (mean reduction), same value as
+    ``CTCLoss(blank)(log_softmax(logits), ...)`` in the reference (train.py:69-77)."""
+    return _CTCLossFn.apply(logits, labels, input_lengths, label_lengths, blank, time_major,
+                            max_label_len)
+
+
+# ------------------------------------------------------------------------------------------
+# Greedy decode (decoder.py:28-57)
+# ------------------------------------------------------------------------------------------
+def greedy_decode_ids(scores, blank=0, frame_lengths=None):
+    """scores [B,T,V] (f32/f16/bf16, device) -> (ids int32 [B,T] padded with -1, lengths int32 [B])."""
+    _need_cuda(scores, "scores")
+    if scores.dim() != 3:
+        raise ValueError("scores must be [B, T, V]")
+    scores = scores.contiguous()
+    B, T, V = scores.shape
+    ids = torch.empty((B, T), dtype=torch.int32, device=scores.device)
+    lengths = torch.empty(B, dtype=torch.int32, device=scores.device)
+    fl = None
+    if frame_lengths is not None:
+        fl = frame_lengths.to(device=scores.device, dtype=torch.int32).contiguous()
+    with torch.cuda.device(scores.device):
+        check(lib().sp_greedy_decode(ptr(scores), _lib.dtype_code(scores), B, T, V, blank, ptr(fl),
+                                     ptr(ids), ptr(lengths), stream_ptr()), "sp_greedy_decode")
+    return ids, lengths
+
+
+def edit_distance(a, b):
+    """Unit-cost Levenshtein distance between two int sequences (host, native)."""
+    a = np.ascontiguousarray(np.asarray(a, dtype=np.int32))
+    b = np.ascontiguousarray(np.asarray(b, dtype=np.int32))
+    r = lib().sp_edit_distance(ctypes.c_void_p(a.ctypes.data), a.size, ctypes.c_void_p(b.ctypes.data), b.size)
+    if r < 0:
+        raise _lib.SpeechHipError("sp_edit_distance failed")
+    return r
+
+
+# ------------------------------------------------------------------------------------------
+# SRU recurrence (net.py:61-72)
+# ------------------------------------------------------------------------------------------
+def sru_fwd(U, xres, wc, bias, mask, T, B, d, k):
+    _need_cuda(U, "U")
+    h = torch.empty((T, B, 2 * d), dtype=U.dtype, device=U.device)
+    c = torch.empty((T, B, 2 * d), dtype=torch.float32, device=U.device)
+    with torch.cuda.device(U.device):
+        check(lib().sp_sru_fwd(ptr(U), ptr(xres), ptr(wc), ptr(bias), ptr(mask), T, B, d, k,
+                               _lib.dtype_code(U), ptr(h), ptr(c), stream_ptr()), "sp_sru_fwd")
+    return h, c
+
+
+def sru_bwd(U, xres, wc, bias, mask, c, gh, T, B, d, k):
+    gU = torch.empty_like(U)
+    gx = torch.empty((T, B, 2 * d), dtype=U.dtype, device=U.device) if k == 3 else None
+    gwc = torch.zeros(4 * d, dtype=torch.float32, device=U.device)
+    gbias = torch.zeros(4 * d, dtype=torch.float32, device=U.device)
+    with torch.cuda.device(U.device):
+        check(lib().sp_sru_bwd(ptr(U), ptr(xres), ptr(wc), ptr(bias), ptr(mask), ptr(c), ptr(gh), T, B,
+                               d, k, _lib.dtype_code(U), ptr(gU), ptr(gx), ptr(gwc), ptr(gbias),
+                               stream_ptr()), "sp_sru_bwd")
+    return gU, gx, gwc, gbias
+
+
+class _SRURecurrenceFn(torch.autograd.Function):
+    """U [T,B,k,2,d], xres [T,B,2d] or None (k == 4), wc/bias [4d] f32, mask [B,2d] f32 or None."""
+
+    @staticmethod
+    def forward(ctx, U, xres, wc, bias, mask, d):
+        T, B = U.shape[0], U.shape[1]
+        k = U.shape[2]
+        U = U.contiguous()
+        xr = xres.contiguous() if xres is not None else None
+        wc32, b32 = wc.float().contiguous(), bias.float().contiguous()
+        h, c = sru_fwd(U, xr, wc32, b32, mask, T, B, d, k)
+        ctx.save_for_backward(U, xr, wc32, b32, mask, c)
+        ctx.dims = (T, B, d, k)
+        ctx.param_dtypes = (wc.dtype, bias.dtype)
+        return h
+
+    @staticmethod
+    def backward(ctx, gh):
+        U, xr, wc32, b32, mask, c = ctx.saved_tensors
+        T, B, d, k = ctx.dims
+        gU, gx, gwc, gbias = sru_bwd(U, xr, wc32, b32, mask, c, gh.contiguous(), T, B, d, k)
+        return gU, gx, gwc.to(ctx.param_dtypes[0]), gbias.to(ctx.param_dtypes[1]), None, None
+
+
+def sru_recurrence(U, xres, wc, bias, mask, d):
+    return _SRURecurrenceFn.apply(U, xres, wc, bias, mask, d)

@@ -18,13 +18,19 @@
 //   K3 ctc_grad    (whole chip, one wave per (t,b) row): posterior per state
 //                  2^(alpha+beta-lp+nll), summed per class in LDS, grad = (softmax - occ)*scale.
 //
-// Workspace (floats): lse2[B*T] | rows[B][T][RW] | alpha[B][T][SP] | beta_rev[B][T][SP].
+// Workspace: lse2[B*T] | rows[B][T][RW] | alpha[B][T][SP] | beta_rev[B][T][SP] (f32), then
+// f64 aoff[B*T] | boff[B*T] | nll2[B].
+//
+// Precision: alpha/beta reach thousands of log2 units, where one f32 ulp is ~2e-4 and a plain
+// f32 log-space recursion (torch's included) random-walks to ~3e-4 relative error in the
+// posteriors.  K2 keeps the lattice states in f64 registers (the adds; exp2/log2 of the small
+// terms stay f32) and spills each row as f32 relative to an f64 per-row offset (the row maximum,
+// refreshed every 4 frames); K3 adds the f64 scalars (aoff + boff - log-likelihood) once per row.
 #include "common.h"
 
 namespace sp {
 
 constexpr float kLog2e = 1.4426950408889634f;
-constexpr float kLn2 = 0.6931471805599453f;
 constexpr int kMaxV = 4000;  // K3 keeps 4 x V floats of per-class sums in LDS (<= 64 KB)
 constexpr int kMaxL = 1023;
 constexpr int kPF = 8;  // float4 prefetch registers per thread in K2
@@ -34,7 +40,9 @@ struct CtcDims {
     int RW;    // row width in floats (multiple of 4)
     int SP;    // padded lattice row (multiple of 8)
     int modeB; // 1: rows indexed by class, 0: by label position
-    size_t off_lse, off_rows, off_alpha, off_beta, total_floats;
+    size_t off_lse, off_rows, off_alpha, off_beta, total_floats;  // float offsets
+    size_t off_dbl;  // float offset of the double block: aoff[B*T] | boff[B*T] | nll2[B]
+    size_t total_bytes;
 };
 
 static CtcDims ctc_dims(int T, int B, int V, int Lmax) {
@@ -48,7 +56,11 @@ static CtcDims ctc_dims(int T, int B, int V, int Lmax) {
     d.off_rows = o; o += (size_t)B * T * d.RW;
     d.off_alpha = o; o += (size_t)B * T * d.SP;
     d.off_beta = o; o += (size_t)B * T * d.SP;
+    o = align_up(o, 4);
+    d.off_dbl = o;
+    o += 2 * ((size_t)2 * B * T + B);  // doubles, counted in floats
     d.total_floats = o;
+    d.total_bytes = o * sizeof(float);
     return d;
 }
 
@@ -96,22 +108,30 @@ __global__ __launch_bounds__(256) void ctc_rows_kernel(
 // -------------------------------------------------------------------------------------------
 // K2: alpha / beta lattice
 // -------------------------------------------------------------------------------------------
-__device__ __forceinline__ float lane_shr1(float v) {
-    // lane i receives lane i-1's value; lane 0 receives -inf
-    const float ninf = -INFINITY;
-    return __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(ninf), __float_as_int(v),
-                                                      0x138 /*wave_shr:1*/, 0xF, 0xF, false));
+__device__ __forceinline__ int lane_shr1_i(int v, int fill) {
+    // lane i receives lane i-1's value; lane 0 receives `fill`
+    return __builtin_amdgcn_update_dpp(fill, v, 0x138 /*wave_shr:1*/, 0xF, 0xF, false);
+}
+__device__ __forceinline__ double lane_shr1(double v) {
+    // -inf as f64 = 0xFFF00000'00000000
+    const int lo = lane_shr1_i(__double2loint(v), 0);
+    const int hi = lane_shr1_i(__double2hiint(v), (int)0xFFF00000);
+    return __hiloint2double(hi, lo);
 }
 
-__device__ __forceinline__ float lse2_3(float a, float b, float c) {
-    float m = fmaxf(a, fmaxf(b, c));
-    const float m2 = (m == -INFINITY) ? 0.f : m;
-    return m2 + log2f(exp2f(a - m2) + exp2f(b - m2) + exp2f(c - m2));
+// log2(2^a + 2^b + 2^c): differences and the final add in f64 (alpha reaches thousands of log2
+// units; an f32 add there costs 2e-4 per step), exp2/log2 of the small terms in f32.
+__device__ __forceinline__ double lse2_3(double a, double b, double c) {
+    const double m = fmax(a, fmax(b, c));
+    const double m2 = (m == -(double)INFINITY) ? 0.0 : m;
+    const float s = exp2f((float)(a - m2)) + exp2f((float)(b - m2)) + exp2f((float)(c - m2));
+    return m2 + (double)log2f(s);
 }
-__device__ __forceinline__ float lse2_2(float a, float b) {
-    float m = fmaxf(a, b);
-    const float m2 = (m == -INFINITY) ? 0.f : m;
-    return m2 + log2f(exp2f(a - m2) + exp2f(b - m2));
+__device__ __forceinline__ double lse2_2(double a, double b) {
+    const double m = fmax(a, b);
+    const double m2 = (m == -(double)INFINITY) ? 0.0 : m;
+    const float s = exp2f((float)(a - m2)) + exp2f((float)(b - m2));
+    return m2 + (double)log2f(s);
 }
 
 template <int W, int NS>
@@ -119,12 +139,14 @@ __global__ __launch_bounds__(64 * W) void ctc_lattice_kernel(
     const float* __restrict__ rows, const int64_t* __restrict__ labels, int label_stride,
     const int32_t* __restrict__ in_len, const int32_t* __restrict__ lab_len, int T, int V,
     int blank, int Lmax, int RW, int SP, int modeB, int TB, float* __restrict__ alpha,
-    float* __restrict__ beta_rev, float* __restrict__ nll) {
+    float* __restrict__ beta_rev, double* __restrict__ aoff, double* __restrict__ boff,
+    double* __restrict__ nll2, float* __restrict__ nll) {
     constexpr int NT = 64 * W;
     // LDS: two row-chunk buffers of kPF*NT float4 each, then boundary slots, then final pair
     __shared__ __attribute__((aligned(16))) float4 s_chunk[2][kPF * NT];
-    __shared__ float s_bnd[2][W][2];
-    __shared__ float s_fin[2];
+    __shared__ double s_bnd[2][W][2];  // per wave: last state, second-to-last
+    __shared__ double s_fin[2];
+    __shared__ float s_max[W];
 
     const int b = blockIdx.x, dir = blockIdx.y;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -133,10 +155,14 @@ __global__ __launch_bounds__(64 * W) void ctc_lattice_kernel(
     const int S = 2 * L + 1;
     const int64_t* lab = labels + (int64_t)b * label_stride;
     float* out = (dir ? beta_rev : alpha) + (int64_t)b * T * SP;
+    double* ooff = (dir ? boff : aoff) + (int64_t)b * T;
     const float* rows_b = rows + (int64_t)b * T * RW;
 
     if (Tb == 0) {
-        if (dir == 0 && tid == 0) nll[b] = (L == 0) ? 0.f : INFINITY;
+        if (dir == 0 && tid == 0) {
+            nll[b] = (L == 0) ? 0.f : INFINITY;
+            nll2[b] = (L == 0) ? 0.0 : (double)INFINITY;
+        }
         return;
     }
 
@@ -187,10 +213,12 @@ __global__ __launch_bounds__(64 * W) void ctc_lattice_kernel(
     SP_CTC_COMMIT(0);
     __syncthreads();
 
-    float a[NS];
+    const double kNegInf = -(double)INFINITY;
+    double a[NS];
 #pragma unroll
-    for (int j = 0; j < NS; ++j) a[j] = -INFINITY;
+    for (int j = 0; j < NS; ++j) a[j] = kNegInf;
 
+    double offs = 0.0;  // f64 offset the stored f32 rows are relative to: true alpha = stored + offs
     int i = 0;
     for (int c = 0; c < nchunks; ++c) {
         if (c + 1 < nchunks) SP_CTC_ISSUE(c + 1);
@@ -206,42 +234,60 @@ __global__ __launch_bounds__(64 * W) void ctc_lattice_kernel(
 #pragma unroll
                 for (int j = 0; j < NS; ++j) {
                     const int sp_ = tid * NS + j;
-                    a[j] = (valid[j] && sp_ < 2) ? lp[j] : -INFINITY;
+                    a[j] = (valid[j] && sp_ < 2) ? (double)lp[j] : kNegInf;
                 }
             } else {
-                float p1 = lane_shr1(a[NS - 1]);
-                float p2 = lane_shr1(a[NS - 2]);
+                double p1 = lane_shr1(a[NS - 1]);
+                double p2 = lane_shr1(a[NS - 2]);
                 if (W > 1) {
                     if (lane == 0 && wave > 0) {
                         p1 = s_bnd[i & 1][wave - 1][0];
                         p2 = s_bnd[i & 1][wave - 1][1];
                     }
                 }
-                float n_[NS];
+                double n_[NS];
 #pragma unroll
                 for (int j = 0; j < NS; ++j) {
-                    const float x1 = (j >= 1) ? a[j - 1] : p1;
-                    const float x2 = (j >= 2) ? a[j - 2] : (j == 1 ? p1 : p2);
+                    const double x1 = (j >= 1) ? a[j - 1] : p1;
+                    const double x2 = (j >= 2) ? a[j - 2] : (j == 1 ? p1 : p2);
                     // j == 1: s'-2 is the previous lane's last state (p1); j == 0: its second-to-last
-                    const float x2s = skip[j] ? x2 : -INFINITY;
-                    n_[j] = valid[j] ? lse2_3(a[j], x1, x2s) + lp[j] : -INFINITY;
+                    const double x2s = skip[j] ? x2 : kNegInf;
+                    n_[j] = valid[j] ? lse2_3(a[j], x1, x2s) + (double)lp[j] : kNegInf;
                 }
 #pragma unroll
                 for (int j = 0; j < NS; ++j) a[j] = n_[j];
             }
-            // spill the lattice row (coalesced, vector stores)
+            // every 4th frame: refresh the storage offset with this row's maximum (uniform branch)
+            if ((i & 3) == 0) {
+                double mx = kNegInf;
+#pragma unroll
+                for (int j = 0; j < NS; ++j) mx = fmax(mx, a[j]);
+                float mxf = wave_max((float)mx);  // an f32 max is plenty for an offset
+                if (W > 1) {
+                    if (lane == 0) s_max[wave] = mxf;
+                    __syncthreads();
+#pragma unroll
+                    for (int w = 0; w < W; ++w) mxf = fmaxf(mxf, s_max[w]);
+                }
+                if (mxf != -INFINITY) offs = (double)mxf;
+            }
+            // spill the lattice row relative to offs (coalesced, vector stores)
+            float st_[NS];
+#pragma unroll
+            for (int j = 0; j < NS; ++j) st_[j] = (float)(a[j] - offs);
             float* orow = out + (int64_t)t * SP + tid * NS;
             if (tid * NS < SP) {
                 if constexpr (NS == 2) {
-                    *reinterpret_cast<float2*>(orow) = make_float2(a[0], a[1]);
+                    *reinterpret_cast<float2*>(orow) = make_float2(st_[0], st_[1]);
                 } else if constexpr (NS == 4) {
-                    *reinterpret_cast<float4*>(orow) = make_float4(a[0], a[1], a[2], a[3]);
+                    *reinterpret_cast<float4*>(orow) = make_float4(st_[0], st_[1], st_[2], st_[3]);
                 } else {
-                    *reinterpret_cast<float4*>(orow) = make_float4(a[0], a[1], a[2], a[3]);
+                    *reinterpret_cast<float4*>(orow) = make_float4(st_[0], st_[1], st_[2], st_[3]);
                     if (tid * NS + 4 < SP)
-                        *reinterpret_cast<float4*>(orow + 4) = make_float4(a[4], a[5], a[6], a[7]);
+                        *reinterpret_cast<float4*>(orow + 4) = make_float4(st_[4], st_[5], st_[6], st_[7]);
                 }
             }
+            if (tid == 0) ooff[t] = offs;
             if (W > 1) {
                 if (lane == 63) {
                     s_bnd[(i + 1) & 1][wave][0] = a[NS - 1];
@@ -263,8 +309,9 @@ __global__ __launch_bounds__(64 * W) void ctc_lattice_kernel(
         }
         __syncthreads();
         if (tid == 0) {
-            const float e = (S > 1) ? lse2_2(s_fin[0], s_fin[1]) : s_fin[0];
-            nll[b] = -e * kLn2;
+            const double ll2 = (S > 1) ? lse2_2(s_fin[0], s_fin[1]) : s_fin[0];  // log2 likelihood
+            nll2[b] = -ll2;
+            nll[b] = (float)(-ll2 * 0.69314718055994530942);
         }
     }
 }
@@ -277,8 +324,10 @@ __global__ __launch_bounds__(256) void ctc_grad_kernel(
     int label_stride, const int32_t* __restrict__ in_len, const int32_t* __restrict__ lab_len,
     int T, int B, int V, int blank, int Lmax, int RW, int SP, int modeB,
     const float* __restrict__ lse2, const float* __restrict__ rows, const float* __restrict__ alpha,
-    const float* __restrict__ beta_rev, const float* __restrict__ nll, float grad_scale,
-    float* __restrict__ grad, float* __restrict__ loss) {
+    const float* __restrict__ beta_rev, const double* __restrict__ aoff,
+    const double* __restrict__ boff, const double* __restrict__ nll2d,
+    const float* __restrict__ nll, float grad_scale, float* __restrict__ grad,
+    float* __restrict__ loss) {
     extern __shared__ __attribute__((aligned(16))) float s_occ[];  // [waves][V]
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int wpb = blockDim.x >> 6;
@@ -303,7 +352,7 @@ __global__ __launch_bounds__(256) void ctc_grad_kernel(
         }
         const int L = min(max(lab_len[b], 0), Lmax);
         const int S = 2 * L + 1;
-        const float nll2 = nll[b] * kLog2e;
+        const float nll2 = (float)(aoff[(int64_t)b * T + t] + boff[(int64_t)b * T + t] + nll2d[b]);
         const float scale = grad_scale / ((float)B * (float)max(L, 1));
         const float* arow = alpha + ((int64_t)b * T + t) * SP;
         const float* brow = beta_rev + ((int64_t)b * T + t) * SP;
@@ -316,7 +365,7 @@ __global__ __launch_bounds__(256) void ctc_grad_kernel(
             int cls = blank;
             if (s & 1) cls = min(max((int)lab[(s - 1) >> 1], 0), V - 1);
             const int ri = modeB ? cls : ((s & 1) ? (s + 1) >> 1 : 0);
-            const float gam = exp2f(arow[s] + brow[S - 1 - s] - lrow[ri] + nll2);
+            const float gam = exp2f((arow[s] + brow[S - 1 - s] - lrow[ri]) + nll2);
             if (s & 1) atomicAdd(&occ[cls], gam);
             else blank_acc += gam;
         }
@@ -337,19 +386,21 @@ template <int W, int NS>
 static void launch_lattice(const CtcDims& d, float* ws, const int64_t* labels, int label_stride,
                            const int32_t* in_len, const int32_t* lab_len, int blank, float* nll,
                            hipStream_t s) {
+    double* dbl = reinterpret_cast<double*>(ws + d.off_dbl);
     int TB = (kPF * 64 * W * 4) / d.RW;
     if (TB > 64) TB = 64;
     if (TB < 1) TB = 1;
     hipLaunchKernelGGL((ctc_lattice_kernel<W, NS>), dim3(d.B, 2), dim3(64 * W), 0, s,
                        ws + d.off_rows, labels, label_stride, in_len, lab_len, d.T, d.V, blank,
-                       d.Lmax, d.RW, d.SP, d.modeB, TB, ws + d.off_alpha, ws + d.off_beta, nll);
+                       d.Lmax, d.RW, d.SP, d.modeB, TB, ws + d.off_alpha, ws + d.off_beta,
+                       dbl, dbl + (size_t)d.B * d.T, dbl + (size_t)2 * d.B * d.T, nll);
 }
 
 }  // namespace sp
 
 extern "C" size_t sp_ctc_workspace_bytes(int T, int B, int V, int max_label_len) {
     if (T < 0 || B < 0 || V < 1 || max_label_len < 0) return 0;
-    return sp::ctc_dims(T, B, V, max_label_len).total_floats * sizeof(float) + 256;
+    return sp::ctc_dims(T, B, V, max_label_len).total_bytes + 256;
 }
 
 extern "C" int sp_ctc_fwd_bwd(const float* logits, int64_t stride_t, int64_t stride_b,
@@ -369,12 +420,13 @@ extern "C" int sp_ctc_fwd_bwd(const float* logits, int64_t stride_t, int64_t str
     SP_CHECK_ARG(logits && input_lengths && label_lengths && nll, "sp_ctc_fwd_bwd: null pointer");
     SP_CHECK_ARG(labels || max_label_len == 0, "sp_ctc_fwd_bwd: null labels");
     const CtcDims d = ctc_dims(T, B, V, max_label_len);
-    if (workspace_bytes < d.total_floats * sizeof(float) || !workspace)
+    if (workspace_bytes < d.total_bytes || !workspace)
         return fail(SP_EWORKSPACE, "sp_ctc_fwd_bwd: workspace %zu < required %zu", workspace_bytes,
-                    d.total_floats * sizeof(float));
+                    d.total_bytes);
     SP_CHECK_ARG(((uintptr_t)workspace & 15) == 0, "sp_ctc_fwd_bwd: workspace must be 16-byte aligned");
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
     float* ws = reinterpret_cast<float*>(workspace);
+    const double* dbl = reinterpret_cast<const double*>(ws + d.off_dbl);
     const int64_t nrows = (int64_t)T * B;
     const int row_blocks = (int)((nrows + 3) / 4 > 4096 ? 4096 : (nrows + 3) / 4);
 
@@ -401,8 +453,8 @@ extern "C" int sp_ctc_fwd_bwd(const float* logits, int64_t stride_t, int64_t str
         hipLaunchKernelGGL(ctc_grad_kernel, dim3(gb), dim3(256), lds, s, logits, stride_t, stride_b,
                            labels, label_stride, input_lengths, label_lengths, T, B, V, blank,
                            max_label_len, d.RW, d.SP, d.modeB, ws + d.off_lse, ws + d.off_rows,
-                           ws + d.off_alpha, ws + d.off_beta, nll, grad_scale, T > 0 ? grad : nullptr,
-                           loss);
+                           ws + d.off_alpha, ws + d.off_beta, dbl, dbl + (size_t)B * T,
+                           dbl + (size_t)2 * B * T, nll, grad_scale, T > 0 ? grad : nullptr, loss);
         rc = check_launch("ctc_grad_kernel");
         if (rc) return rc;
     }

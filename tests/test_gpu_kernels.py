@@ -6,9 +6,11 @@ Tolerances (written where used):
   mel     |hip - oracle| <= 1e-4 * max|oracle| per utterance (north_star: 1e-4 relative in fp32; a
           per-element relative test is meaningless in near-zero-energy bins, so the floor is the
           utterance's peak).
-  ctc     loss/nll 1e-4 relative; gradient |hip - ref| <= 1e-4 * max|ref| + tiny: alpha/beta reach
-          magnitudes of thousands of nats, where one fp32 ulp is ~2e-4, so torch's own fp32 kernel
-          is only this accurate per element; the float64 oracle is the tie-breaker.
+  ctc     loss/nll 1e-4 relative.  Gradient: |hip - ref64| <= 1e-4 * max|ref64| against the
+          reference's CTC evaluated in float64 (torch CPU, dtype=float64).  Against the reference's
+          own fp32 run the bound is 1e-4 * max + 2 * |ref32 - ref64|: alpha/beta reach thousands of
+          nats where one fp32 ulp is ~2e-4, so torch's fp32 CTC itself is off by a few 1e-4 relative
+          at T >= 100 (measured in the test), which no implementation can track element by element.
 """
 import json
 import os
@@ -184,7 +186,13 @@ def test_ctc_golden(cuda, golden_dir, name, time_major):
     assert loss == pytest.approx(float(g[name + "__loss"]), rel=1e-4)          # 1e-4 relative
     assert np.allclose(nll, g[name + "__nll"], rtol=1e-4, atol=1e-5)
     gref = g[name + "__grad"]
-    assert np.abs(grad - gref).max() <= 1e-4 * np.abs(gref).max() + 1e-9
+    _, _, g64 = octc.ctc_torch(g[name + "__logits"], g[name + "__labels"], g[name + "__input_lengths"],
+                               g[name + "__label_lengths"], dtype=torch.float64)
+    g64 = g64.numpy()
+    gmax = np.abs(g64).max()
+    assert np.abs(grad - g64).max() <= 1e-4 * gmax + 1e-12
+    ref32_err = np.abs(gref - g64).max()
+    assert np.abs(grad - gref).max() <= 1e-4 * gmax + 2 * ref32_err + 1e-12
     # frames past input_length carry exactly zero gradient
     il = g[name + "__input_lengths"]
     for b, tb in enumerate(il):
@@ -199,7 +207,7 @@ def test_ctc_infeasible_is_inf(cuda, golden_dir):
     assert np.isinf(nll).all() and np.isinf(loss)
 
 
-@pytest.mark.parametrize("cfg", [(751, 8, 29, 225), (300, 4, 1000, 60), (1501, 2, 29, 450), (200, 3, 29, 600)])
+@pytest.mark.parametrize("cfg", [(751, 8, 29, 225), (300, 4, 1000, 60), (1501, 2, 29, 450), (700, 3, 29, 600)])
 def test_ctc_seeded_vs_oracles(cuda, cfg):
     """Sizes the CPU finishes in seconds: against torch CPU fp32 (the reference) and float64."""
     T, B, V, L = cfg
@@ -216,11 +224,12 @@ def test_ctc_seeded_vs_oracles(cuda, cfg):
     assert np.allclose(nll, rnll.numpy(), rtol=1e-4)
     feasible = np.isfinite(rnll.numpy())
     assert feasible.any()
-    gmax = np.abs(rgrad.numpy()[:, feasible]).max()
-    assert np.abs(grad[:, feasible] - rgrad.numpy()[:, feasible]).max() <= 1e-4 * gmax + 1e-9
-    if T * B <= 2500:  # float64 tie-breaker where the pure-numpy oracle is fast enough
-        l64, n64, g64 = octc.ctc_numpy(logits.numpy(), labels.numpy(), il.numpy(), ll.numpy())
-        assert np.abs(grad[:, feasible] - g64[:, feasible]).max() <= 1e-4 * gmax + 1e-9
+    _, _, g64 = octc.ctc_torch(logits, labels, il, ll, dtype=torch.float64)
+    g64 = g64.numpy()[:, feasible]
+    gmax = np.abs(g64).max()
+    assert np.abs(grad[:, feasible] - g64).max() <= 1e-4 * gmax + 1e-12
+    ref32_err = np.abs(rgrad.numpy()[:, feasible] - g64).max()
+    assert np.abs(grad[:, feasible] - rgrad.numpy()[:, feasible]).max() <= 1e-4 * gmax + 2 * ref32_err + 1e-12
 
 
 def test_ctc_autograd_wrapper(cuda):

@@ -1,0 +1,245 @@
+#!/usr/bin/env python
+"""Headline benchmark: training throughput (audio-seconds per second) of the full hot path --
+fused mel frontend -> encoder forward/backward -> fused CTC loss/grad -> clip + Adam -- on
+BASELINE.json configs[1]: synthetic 16 kHz audio, batch 32 x 15 s per GPU, 80 mels, SentencePiece-
+sized vocabulary (999 pieces + blank), bf16 activations.
+
+    python bench.py --gpus 1 --steps 20 --warmup 5
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \\
+        --master-port P bench.py --gpus N --steps K --warmup W
+
+Prints ONE JSON line on rank 0.  Inputs (waveforms, labels) are resident in HBM before the timed
+region; the SpecAugment draws (a [B,4] int32 tensor) are made on the host every step like the
+reference does.  `roofline` is measured live with HIP events on the kernels' own stream;
+`cpu_baseline` times the CPU oracle (oracle/) on a bounded sample on rank 0 at N=1.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import torch
+import torch.distributed as dist
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0      # MI355X_MICROARCH.md: HBM3E 8 TB/s
+MFMA_BF16_PEAK_TF = 2500.0  # dense bf16
+
+
+def parse():
+    p = argparse.ArgumentParser()
+    p.add_argument("--gpus", type=int, default=1)
+    p.add_argument("--steps", type=int, default=20)
+    p.add_argument("--warmup", type=int, default=5)
+    p.add_argument("--batch", type=int, default=32)
+    p.add_argument("--seconds", type=float, default=15.0)
+    p.add_argument("--vocab", choices=["sp", "char"], default="sp")
+    p.add_argument("--dtype", choices=["bf16", "fp32"], default="bf16")
+    p.add_argument("--no-cpu-baseline", action="store_true")
+    p.add_argument("--kernel-iters", type=int, default=20)
+    return p.parse_args()
+
+
+def synth_batch(B, N, V, seconds, device, vocab):
+    """0.1*randn clamp + one sine per utterance; labels U{1..V-1}, length
+    U[0.5,1] * (15 chars/s or 4 pieces/s) * duration, some adjacent repeats forced."""
+    g = torch.Generator(device="cpu").manual_seed(7)
+    t = torch.arange(N, dtype=torch.float32) / 16000.0
+    freqs = torch.randint(80, 4000, (B, 1), generator=g).float()
+    wav = (0.1 * torch.randn(B, N, generator=g) + 0.2 * torch.sin(2 * torch.pi * freqs * t)).clamp(-1, 1)
+    per_s = 15.0 if vocab == "char" else 4.0
+    Lmax = int(per_s * seconds)
+    lens = (torch.rand(B, generator=g) * 0.5 + 0.5).mul(Lmax).long().clamp(min=1)
+    lens[0] = Lmax
+    labels = torch.randint(1, V, (B, Lmax), generator=g)
+    labels[:, 1::9] = labels[:, 0::9][:, : labels[:, 1::9].shape[1]]
+    offs = torch.arange(B + 1, dtype=torch.int64) * N
+    return (wav.reshape(-1).to(device), offs.to(device), labels.to(device),
+            lens.to(torch.int32).to(device), Lmax)
+
+
+def time_kernel(fn, iters):
+    """Average device time of fn() in ms, HIP events on the current stream (the stream the C-ABI
+    launches use: speech_amd passes torch's current stream)."""
+    for _ in range(3):
+        fn()
+    start, end = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    torch.cuda.synchronize()
+    start.record()
+    for _ in range(iters):
+        fn()
+    end.record()
+    torch.cuda.synchronize()
+    return start.elapsed_time(end) / iters
+
+
+def kernel_rooflines(args, model, wav, offs, labels, lens, Lmax, V, iters):
+    """Per-kernel HBM / MFMA roofline lines for the hand-written kernels, measured live."""
+    from speech_amd import ops
+    dev = wav.device
+    B, N = args.batch, int(args.seconds * 16000)
+    out = {}
+    # frontend: 4*sum(N) + 4*80*B*Tmax bytes
+    masks = torch.tensor([[10, 10, 100, 30]] * B, dtype=torch.int32, device=dev)
+    T = 1 + N // 160
+    spec_buf = torch.empty((B, 1, 80, T), dtype=torch.float32, device=dev)
+    ms = time_kernel(lambda: ops.melspec(wav, offs, masks=masks, out=spec_buf), iters)
+    by = 4.0 * B * N + 4.0 * 80 * B * T
+    out["melspec_kernel"] = {"bound": "hbm", "achieved": by / ms / 1e6, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                             "frac": by / ms / 1e6 / HBM_PEAK_GBS, "ms": ms, "algorithmic_bytes": by}
+    # CTC: scores read + grad write + lattice write/read (2*4*sum T'*S_b)
+    Tp = (T - 1) // 2 + 1
+    logits = torch.randn(B, Tp, V, device=dev) * 3
+    il = torch.full((B,), Tp, dtype=torch.int32, device=dev)
+    ms = time_kernel(lambda: ops.ctc_fwd_bwd(logits, labels, il, lens, max_label_len=Lmax), iters)
+    S = (2 * lens.float() + 1).sum().item()
+    by = 2 * 4.0 * Tp * B * V + 2 * 4.0 * Tp * S
+    out["ctc_fwd_bwd(3 kernels)"] = {"bound": "hbm", "achieved": by / ms / 1e6, "peak": HBM_PEAK_GBS,
+                                     "unit": "GB/s", "frac": by / ms / 1e6 / HBM_PEAK_GBS, "ms": ms,
+                                     "algorithmic_bytes": by}
+    # decode: scores read + ids write
+    ms = time_kernel(lambda: ops.greedy_decode_ids(logits), iters)
+    by = 4.0 * B * Tp * V + 4.0 * B * Tp
+    out["greedy_decode_kernel"] = {"bound": "hbm", "achieved": by / ms / 1e6, "peak": HBM_PEAK_GBS,
+                                   "unit": "GB/s", "frac": by / ms / 1e6 / HBM_PEAK_GBS, "ms": ms,
+                                   "algorithmic_bytes": by}
+    # SRU recurrence forward, one k=3 layer: U + xres read, h + c written
+    d = 512
+    e = 2 if args.dtype == "bf16" else 4
+    adt = torch.bfloat16 if args.dtype == "bf16" else torch.float32
+    U = torch.randn(Tp, B, 3, 2, d, device=dev).to(adt)
+    xr = torch.randn(Tp, B, 2 * d, device=dev).to(adt)
+    wc = torch.randn(4 * d, device=dev) * 0.5
+    bias = torch.zeros(4 * d, device=dev)
+    ms = time_kernel(lambda: ops.sru_fwd(U, xr, wc, bias, None, Tp, B, d, 3), iters)
+    by = Tp * B * 2 * d * (3 * e + e + e + 4.0)
+    out["sru_fwd_kernel"] = {"bound": "hbm", "achieved": by / ms / 1e6, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                             "frac": by / ms / 1e6 / HBM_PEAK_GBS, "ms": ms, "algorithmic_bytes": by}
+    h, c = ops.sru_fwd(U, xr, wc, bias, None, Tp, B, d, 3)
+    gh = torch.randn_like(h)
+    ms = time_kernel(lambda: ops.sru_bwd(U, xr, wc, bias, None, c, gh, Tp, B, d, 3), iters)
+    by = Tp * B * 2 * d * (3 * e + e + e + 4.0 + 3 * e + e)
+    out["sru_bwd_kernel"] = {"bound": "hbm", "achieved": by / ms / 1e6, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                             "frac": by / ms / 1e6 / HBM_PEAK_GBS, "ms": ms, "algorithmic_bytes": by}
+    return out
+
+
+def cpu_baseline(args, V):
+    """The CPU oracle (oracle.mel + oracle.net + torch CPU CTC + torch Adam: the reference's own
+    CPU arithmetic) on a bounded sample: ONE training step on 2 utterances of the same length."""
+    from oracle import mel as omel
+    from oracle import net as onet
+    from speech_amd import net as pnet
+    cores = min(16, os.cpu_count() or 1)
+    torch.set_num_threads(cores)
+    Bs = 2
+    N = int(args.seconds * 16000)
+    g = torch.Generator().manual_seed(7)
+    wavs = [(0.1 * torch.randn(1, N, generator=g)).clamp(-1, 1) for _ in range(Bs)]
+    L = int((15.0 if args.vocab == "char" else 4.0) * args.seconds)
+    labels = torch.randint(1, V, (Bs, L), generator=g)
+    ll = torch.full((Bs,), L, dtype=torch.int32)
+    model = pnet.SRModel(10, 512, V - 1, 80, 0.1, 0)
+    sd = {k: v.detach().clone() for k, v in model.state_dict().items()}
+    t0 = time.time()
+    spec = omel.collate(wavs, masks=[(10, 10, 100, 30)] * Bs)
+    loss, grads, _ = onet.loss_and_grads(sd, spec, labels, ll, 10, 512, training=True)
+    params = [sd[k].requires_grad_(False) for k in grads]
+    opt = torch.optim.Adam([torch.nn.Parameter(p) for p in params], lr=3e-4)
+    for p, k in zip(opt.param_groups[0]["params"], grads):
+        p.grad = grads[k]
+    torch.nn.utils.clip_grad_norm_(opt.param_groups[0]["params"], 2.0)
+    opt.step()
+    dt = time.time() - t0
+    return {"value": Bs * args.seconds / dt, "unit": "audio-sec/sec", "cores": cores, "kind": "port",
+            "sample": f"1 training step on {Bs} x {args.seconds:g} s utterances (fp32, CPU oracle: torch.stft mel, "
+                      f"torch conv/BN/GEMM, python-loop SRU, torch CTC, torch Adam), {dt:.1f} s wall"}
+
+
+def main():
+    args = parse()
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus and world > 1:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    if args.gpus > 1 and world == 1:
+        raise SystemExit("launch multi-GPU runs with torch.distributed.run (one process per GPU)")
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=dev)
+
+    from speech_amd import data, net, ops
+    from speech_amd.train import BucketedAllReduce, FlatAdam, lr_lambda_linear_warmup, train_step
+
+    V = 1000 if args.vocab == "sp" else 29
+    B, N = args.batch, int(args.seconds * 16000)
+    adt = torch.bfloat16 if args.dtype == "bf16" else torch.float32
+    torch.manual_seed(7)
+    model = net.SRModel(10, 512, V - 1, 80, 0.1, 0, compute_dtype=adt).to(dev)
+    model.train()
+    opt = FlatAdam(model.parameters(), lr=3e-4, weight_decay=1e-3)
+    dp = BucketedAllReduce(opt) if world > 1 else None
+    torch.manual_seed(7 + rank)
+    wav, offs, labels, lens, Lmax = synth_batch(B, N, V, args.seconds, dev, args.vocab)
+    T = 1 + N // 160
+
+    def step(i):
+        masks = data.draw_masks([T] * B)                      # host RNG, like the reference
+        spec = ops.melspec(wav, offs, masks=masks)
+        opt.param_groups[0]["lr"] = 3e-4 * lr_lambda_linear_warmup(i + 1, 3500, 10 ** 6)
+        return train_step(model, opt, spec, labels, lens, 2.0, dp, max_label_len=Lmax)
+
+    for i in range(args.warmup):
+        loss = step(i)
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        loss = step(args.warmup + i)
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    dt = time.perf_counter() - t0
+    tmax = torch.tensor([dt], dtype=torch.float64, device=dev)
+    if world > 1:
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+    dt = float(tmax.item())
+    loss_val = float(loss)
+
+    if rank == 0:
+        value = B * args.seconds * world * args.steps / dt
+        line = {
+            "metric": "train audio-sec/sec", "value": value, "unit": "audio-sec/sec", "n_gpus": world,
+            "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1000.0 * dt / args.steps,
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": args.dtype,
+            "data": "synthetic",
+            "config": {"workload": f"configs[1]: synthetic 16 kHz, batch {B} x {args.seconds:g} s per GPU, 80 mels, "
+                                   f"{'sentencepiece-sized vocab (999+blank)' if args.vocab == 'sp' else 'char vocab (29)'}"
+                                   ", full training step (mel frontend + SRModel fwd/bwd + CTC + clip + Adam)",
+                       "global_batch": B * world, "seconds_per_utt": args.seconds, "vocab": V,
+                       "parallelism": f"dp{world}", "final_loss": loss_val},
+        }
+        if world == 1:
+            ks = kernel_rooflines(args, model, wav, offs, labels, lens, Lmax, V, args.kernel_iters)
+            dom = max(ks, key=lambda k: ks[k]["ms"])
+            r = dict(ks[dom])
+            r["kernel"] = dom
+            r["traffic"] = None
+            line["roofline"] = {k: r[k] for k in ("bound", "achieved", "peak", "unit", "frac", "traffic", "kernel")}
+            line["kernels"] = ks
+            if not args.no_cpu_baseline:
+                line["cpu_baseline"] = cpu_baseline(args, V)
+        print(json.dumps(line), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -117,6 +117,20 @@ int sp_sru_bwd(const void* U, const void* xres, const float* wc, const float* bi
                const float* mask, const float* c, const void* gh, int T, int B, int d, int k,
                int dtype, void* gU, void* gxres, float* gwc, float* gbias, void* stream);
 
+/* ---------------------------------------------------------------------------------------
+ * Optimizer step over a flat fp32 arena.  Replaces train.py:81-85 (clip_grad_norm_ over all
+ * parameters, then bitsandbytes Adam8bit.step()).
+ * sp_sumsq_f32: out[0] = sum x_i^2 (out is zeroed on the stream first).
+ * sp_adam_step_f32: bias-corrected Adam, step >= 1.  Gradient used = g * clip / grad_div where
+ * clip = min(1, max_norm / (sqrt(sumsq[0]) + 1e-6)) if sumsq != NULL and max_norm > 0, else 1
+ * (clip_grad_norm_ semantics, no host sync).  decoupled != 0: p *= 1 - lr*wd after the update
+ * (bitsandbytes kernels); 0: g += wd * p (L2).
+ * --------------------------------------------------------------------------------------- */
+int sp_sumsq_f32(const float* x, int64_t n, float* out, void* stream);
+int sp_adam_step_f32(float* p, const float* g, float* m, float* v, int64_t n, float lr, float beta1,
+                     float beta2, float eps, float weight_decay, int step, int decoupled,
+                     const float* sumsq, float max_norm, float grad_div, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

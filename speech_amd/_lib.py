@@ -29,6 +29,8 @@ SIGNATURES = {
     "sp_sru_fwd": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp, _vp, _vp]),
     "sp_sru_bwd": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp, _vp, _vp, _vp,
                         _vp]),
+    "sp_sumsq_f32": (_i, [_vp, _i64, _vp, _vp]),
+    "sp_adam_step_f32": (_i, [_vp, _vp, _vp, _vp, _i64, _f, _f, _f, _f, _f, _i, _i, _vp, _f, _f, _vp]),
 }
 
 _lib = None
@@ -42,6 +44,9 @@ def lib():
     """Load (once) and return the ctypes handle.  Raises if the library was not built."""
     global _lib
     if _lib is None:
+        # torch ships its own HIP runtime; it must be the one already mapped when this library's
+        # libamdhip64 dependency is resolved, or the process ends up with two runtimes.
+        import torch  # noqa: F401
         if not os.path.exists(LIB_PATH):
             raise SpeechHipError(
                 f"{LIB_PATH} not found: build it with `python -m speech_amd.build` "

@@ -1,0 +1,163 @@
+"""Acoustic encoder -- same module surface and state_dict layout as the reference's net.py:6-87:
+``SRModel(n_rnn_layers, rnn_dim, n_vocab, n_feats, dropout, projection_size)``,
+``forward(x[B,1,n_feats,T]) -> [B,T',n_vocab+1]``.
+
+state_dict keys: cnn.{weight,bias}; resnet_layers.{0,1,2}.{conv1,conv2}.*,
+.{bn1,bn2}.*; sru_layers.rnn_lst.{i}.{weight,weight_c,bias,layer_norm.weight,layer_norm.bias}
+(+ scale_x buffer); classifier.0.{weight,bias}; classifier.1.weight.
+
+The SRU recurrence runs in the HIP kernels (ops.sru_recurrence).  ``compute_dtype`` selects the
+activation type of the encoder: float32 (parity) or bfloat16 (throughput; the reference trains
+under fp16 autocast with an fp16 recurrence, net.py:71).
+"""
+import math
+
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+from . import ops
+
+
+class ResidualBlock(nn.Module):
+    """net.py:6-42: conv(3 x t) -> BN -> ReLU -> conv -> BN -> += residual -> ReLU."""
+
+    def __init__(self, in_channels, out_channels, t_kernel_s):
+        super().__init__()
+        pad = (3 // 2, t_kernel_s // 2)
+        self.conv1 = nn.Conv2d(in_channels, out_channels, (3, t_kernel_s), 1, padding=pad)
+        self.conv2 = nn.Conv2d(out_channels, out_channels, (3, t_kernel_s), 1, padding=pad)
+        self.relu = nn.ReLU(inplace=True)
+        self.bn1 = nn.BatchNorm2d(out_channels)
+        self.bn2 = nn.BatchNorm2d(out_channels)
+        for conv in (self.conv1, self.conv2):
+            nn.init.kaiming_normal_(conv.weight, mode="fan_out", nonlinearity="relu")
+        nn.init.ones_(self.bn1.weight)
+        nn.init.zeros_(self.bn1.bias)
+        nn.init.zeros_(self.bn2.weight)  # blocks start as the identity (net.py:30)
+        nn.init.zeros_(self.bn2.bias)
+
+    def forward(self, x):
+        y = self.relu(self.bn1(self.conv1(x)))
+        y = self.bn2(self.conv2(y))
+        y = y + x
+        return self.relu(y)
+
+
+class SRUCell(nn.Module):
+    """One bidirectional SRU layer with input layer-norm (sru.SRUCell as net.py:61-72 configures it).
+
+    weight [n_in, 2*d*k] with columns ordered (dir, channel, k) -- the package's layout, kept for
+    checkpoint compatibility; the kernels want (k, dir, channel), so the projection uses a
+    permuted view of it.
+    """
+
+    def __init__(self, input_size, hidden_size, dropout=0.0, highway_bias=0.0):
+        super().__init__()
+        self.input_size, self.hidden_size = input_size, hidden_size
+        self.output_size = 2 * hidden_size
+        self.dropout = dropout
+        self.num_matrices = 3 if input_size == self.output_size else 4
+        self.weight = nn.Parameter(torch.empty(input_size, self.output_size * self.num_matrices))
+        self.weight_c = nn.Parameter(torch.empty(2 * self.output_size))
+        self.bias = nn.Parameter(torch.empty(2 * self.output_size))
+        self.register_buffer("scale_x", torch.ones(1))
+        self.layer_norm = nn.LayerNorm(input_size)
+        self.highway_bias = highway_bias
+        self.reset_parameters()
+
+    def reset_parameters(self):
+        """Package defaults as recalled (parity unpinned): W ~ U(+-sqrt(3/n_in)) * 0.1 under layer
+        norm, the u0 columns scaled by sqrt(1-dropout); v ~ U(+-sqrt(3)) * sqrt(0.5); b = 0 with the
+        reset-gate half set to highway_bias."""
+        with torch.no_grad():
+            r = (3.0 / self.input_size) ** 0.5
+            self.weight.uniform_(-r, r)
+            w = self.weight.view(self.input_size, 2, self.hidden_size, self.num_matrices)
+            if self.dropout > 0:
+                w[..., 0].mul_((1 - self.dropout) ** 0.5)
+            self.weight.mul_(0.1)
+            self.weight_c.uniform_(-(3.0 ** 0.5), 3.0 ** 0.5).mul_(0.5 ** 0.5)
+            self.bias.zero_()
+            self.bias[self.output_size:].fill_(self.highway_bias)
+
+    def kernel_weight(self, dtype):
+        """[n_in, k, 2, d] column order for the kernels, flattened, in the compute dtype."""
+        k, d = self.num_matrices, self.hidden_size
+        w = self.weight.view(self.input_size, 2, d, k).permute(0, 3, 1, 2)
+        return w.reshape(self.input_size, k * 2 * d).to(dtype)
+
+    def forward(self, x):
+        T, B, n_in = x.shape
+        k, d = self.num_matrices, self.hidden_size
+        ln = self.layer_norm
+        xn = F.layer_norm(x, (n_in,), ln.weight.to(x.dtype), ln.bias.to(x.dtype), ln.eps)
+        U = (xn.reshape(T * B, n_in) @ self.kernel_weight(x.dtype)).view(T, B, k, 2, d)
+        mask = None
+        if self.training and self.dropout > 0:
+            keep = 1.0 - self.dropout
+            mask = torch.bernoulli(torch.full((B, 2 * d), keep, device=x.device)) / keep
+        return ops.sru_recurrence(U, x if k == 3 else None, self.weight_c, self.bias, mask, d)
+
+
+class SRU(nn.Module):
+    """sru.SRU(input_size, hidden_size, num_layers, dropout, bidirectional=True, layer_norm=True,
+    rescale=False, highway_bias=0): dropout on every layer but the last."""
+
+    def __init__(self, input_size, hidden_size, num_layers, dropout=0.0, projection_size=0,
+                 highway_bias=0.0):
+        super().__init__()
+        if projection_size:
+            raise NotImplementedError("projection_size > 0 (weight_proj) is not built; the reference "
+                                      "trains with projection_size=0 (train.py:319)")
+        self.rnn_lst = nn.ModuleList(
+            SRUCell(input_size if i == 0 else 2 * hidden_size, hidden_size,
+                    dropout=dropout if i + 1 != num_layers else 0.0, highway_bias=highway_bias)
+            for i in range(num_layers))
+
+    def forward(self, x):
+        for cell in self.rnn_lst:
+            x = cell(x)
+        return x, None
+
+
+class SRModel(nn.Module):
+    def __init__(self, n_rnn_layers, rnn_dim, n_vocab, n_feats, dropout, projection_size=0,
+                 compute_dtype=torch.float32):
+        super().__init__()
+        self.cnn = nn.Conv2d(1, 32, 3, stride=2, padding=3 // 2)
+        self.resnet_layers = nn.Sequential(*[ResidualBlock(32, 32, t_kernel_s=5) for _ in range(3)])
+        n_features = 32 * n_feats // 2
+        self.sru_layers = SRU(n_features, rnn_dim, n_rnn_layers, dropout=dropout,
+                              projection_size=projection_size)
+        self.classifier = nn.Sequential(nn.LayerNorm(2 * rnn_dim),
+                                        nn.Linear(2 * rnn_dim, n_vocab + 1, bias=False))
+        self.compute_dtype = compute_dtype
+
+    def forward(self, x):  # [B, 1, F, T]
+        cd = self.compute_dtype
+        if cd == torch.float32:
+            x = self.resnet_layers(self.cnn(x.float()))
+        else:
+            with torch.autocast("cuda", dtype=cd):
+                x = self.resnet_layers(self.cnn(x))
+            x = x.to(cd)
+        B, C, Fq, T = x.shape
+        x = x.reshape(B, C * Fq, T).permute(2, 0, 1).contiguous()  # [T', B, 1280], feature = c*40+f
+        x, _ = self.sru_layers(x)
+        x = x.transpose(0, 1).contiguous()  # [B, T', 2*rnn_dim]
+        ln, lin = self.classifier[0], self.classifier[1]
+        x = F.layer_norm(x, (x.shape[-1],), ln.weight.to(cd), ln.bias.to(cd), ln.eps)
+        return x @ lin.weight.to(cd).t()
+
+    def load_checkpoint(self, obj):
+        """Accept both checkpoint shapes of the reference: the dict train.py:171-178 saves
+        ({"epoch","model_state_dict","optimizer_state_dict"}) and the bare state_dict that
+        scripts/predict.py:35 and scripts/eval_dataset.py:119 load."""
+        sd = obj["model_state_dict"] if isinstance(obj, dict) and "model_state_dict" in obj else obj
+        return self.load_state_dict(sd)
+
+
+def out_frames(t):
+    """Encoder frames for t mel frames: the stride-2 stem (net.py:56)."""
+    return (t - 1) // 2 + 1

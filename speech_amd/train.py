@@ -1,0 +1,317 @@
+"""Training / evaluation loop -- same entry point and flags as the reference's train.py
+(--one_iter --datasets --multiplier --device --weight_decay --clip_grad_norm --dropout
+--learning_rate --num_epochs --projection_size), plus --synthetic / --steps / --dtype.
+
+What changes against train.py:42-304:
+  * features come from the fused HIP frontend on the GPU (data.collate_fn), not DataLoader workers;
+  * log_softmax + transpose + CTCLoss (train.py:69-77) is one fused call (ops.ctc_loss) on the
+    model's [B,T',V] logits -- same value and gradient, no transposed copy;
+  * bf16 activations instead of fp16 autocast + GradScaler (no loss scaling needed), so the
+    reference's clip-before-unscale quirk (train.py:79-83) disappears;
+  * Adam state in fp32 over one flat arena (two launches per step: norm, clip+Adam) instead of
+    bitsandbytes Adam8bit;
+  * data-parallel training: one process per GPU, gradients all-reduced in ~25 MB buckets of the
+    flat gradient arena on RCCL, launched from grad-ready hooks so they overlap the rest of
+    backward (the reference is single-GPU).
+Launch N ranks with ``python -m torch.distributed.run --nproc-per-node N -m speech_amd.train ...``.
+"""
+import argparse
+import ctypes
+import os
+import time
+
+import torch
+import torch.distributed as dist
+
+from . import data, decoder, net, ops
+from ._lib import check, lib, ptr, stream_ptr
+
+
+def lr_lambda_linear_warmup(current_step, num_warmup_steps, num_training_steps):
+    """train.py:17-24: linear warm-up then linear decay to zero."""
+    if current_step < num_warmup_steps:
+        return float(current_step) / float(max(1, num_warmup_steps))
+    return max(0.0, float(num_training_steps - current_step)
+               / float(max(1, num_training_steps - num_warmup_steps)))
+
+
+def get_linear_schedule_with_warmup(optimizer, num_warmup_steps, num_training_steps, last_epoch=-1):
+    return torch.optim.lr_scheduler.LambdaLR(
+        optimizer, lambda s: lr_lambda_linear_warmup(s, num_warmup_steps, num_training_steps), last_epoch)
+
+
+class IterMeter(object):
+    """keeps track of total iterations (train.py:29-39)"""
+
+    def __init__(self):
+        self.val = 0
+
+    def step(self):
+        self.val += 1
+
+    def get(self):
+        return self.val
+
+
+class FlatAdam(torch.optim.Optimizer):
+    """Adam over one flat fp32 arena.  Every parameter's .data and .grad become views into two
+    contiguous buffers (16-byte aligned slices), so the global grad norm, the clip and the update
+    are two kernel launches, and gradient buckets for the all-reduce are plain slices."""
+
+    def __init__(self, params, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.0,
+                 decoupled_weight_decay=True):
+        params = [p for p in params if p.requires_grad]
+        super().__init__(params, dict(lr=lr, betas=betas, eps=eps, weight_decay=weight_decay))
+        self.plist = params
+        dev = params[0].device
+        self.offsets, total = [], 0
+        for p in params:
+            self.offsets.append(total)
+            total += (p.numel() + 3) // 4 * 4
+        self.total = total
+        self.flat = torch.zeros(total, dtype=torch.float32, device=dev)
+        self.flat_grad = torch.zeros(total, dtype=torch.float32, device=dev)
+        self.exp_avg = torch.zeros(total, dtype=torch.float32, device=dev)
+        self.exp_avg_sq = torch.zeros(total, dtype=torch.float32, device=dev)
+        self.sumsq = torch.zeros(1, dtype=torch.float32, device=dev)
+        for p, off in zip(params, self.offsets):
+            n = p.numel()
+            self.flat[off:off + n].copy_(p.data.reshape(-1).float())
+            p.data = self.flat[off:off + n].view(p.shape)
+            p.grad = self.flat_grad[off:off + n].view(p.shape)
+        self.t = 0
+        self.decoupled = decoupled_weight_decay
+
+    def zero_grad(self, set_to_none=False):
+        self.flat_grad.zero_()
+        for p, off in zip(self.plist, self.offsets):  # autograd may have replaced a view
+            if p.grad is None or p.grad.data_ptr() != self.flat_grad.data_ptr() + 4 * off:
+                p.grad = self.flat_grad[off:off + p.numel()].view(p.shape)
+
+    @torch.no_grad()
+    def step(self, max_norm=0.0, grad_div=1.0):
+        g = self.param_groups[0]
+        self.t += 1
+        with torch.cuda.device(self.flat.device):
+            s = stream_ptr()
+            sumsq = None
+            if max_norm and max_norm > 0:
+                check(lib().sp_sumsq_f32(ptr(self.flat_grad), self.total, ptr(self.sumsq), s), "sp_sumsq_f32")
+                sumsq = self.sumsq
+            check(lib().sp_adam_step_f32(ptr(self.flat), ptr(self.flat_grad), ptr(self.exp_avg),
+                                         ptr(self.exp_avg_sq), self.total, float(g["lr"]),
+                                         float(g["betas"][0]), float(g["betas"][1]), float(g["eps"]),
+                                         float(g["weight_decay"]), self.t, int(self.decoupled), ptr(sumsq),
+                                         float(max_norm or 0.0), float(grad_div), s), "sp_adam_step_f32")
+
+    def state_dict(self):
+        return {"t": self.t, "exp_avg": self.exp_avg.clone(), "exp_avg_sq": self.exp_avg_sq.clone(),
+                "param_groups": [{k: v for k, v in self.param_groups[0].items() if k != "params"}]}
+
+    def load_state_dict(self, sd):
+        self.t = sd["t"]
+        self.exp_avg.copy_(sd["exp_avg"])
+        self.exp_avg_sq.copy_(sd["exp_avg_sq"])
+
+
+class BucketedAllReduce:
+    """Data-parallel gradient exchange: the flat gradient arena is cut, from its END (the
+    classifier and the last SRU layers, whose gradients are ready first), into buckets of about
+    ``bucket_mb``; a post-accumulate hook on every parameter counts its bucket down and the bucket's
+    all-reduce (sum; the mean's 1/world is folded into the optimizer's grad_div) is launched
+    asynchronously on RCCL as soon as the bucket is complete, overlapping the rest of backward."""
+
+    def __init__(self, opt, group=None, bucket_mb=25.0):
+        self.opt, self.group = opt, group
+        self.world = dist.get_world_size(group)
+        cap = int(bucket_mb * 1024 * 1024 / 4)
+        self.buckets = []   # [lo, hi, n_params]
+        self.bucket_of = {}
+        hi, count, lo = opt.total, 0, opt.total
+        for idx in range(len(opt.plist) - 1, -1, -1):
+            lo = opt.offsets[idx]
+            count += 1
+            self.bucket_of[idx] = len(self.buckets)
+            if hi - lo >= cap or idx == 0:
+                self.buckets.append([lo, hi, count])
+                hi, count = lo, 0
+        self.pending = [b[2] for b in self.buckets]
+        self.handles = []
+        for idx, p in enumerate(opt.plist):
+            p.register_post_accumulate_grad_hook(self._make_hook(idx))
+        # start from identical replicas
+        dist.broadcast(opt.flat, src=0, group=group)
+
+    def _make_hook(self, idx):
+        def hook(_param):
+            b = self.bucket_of[idx]
+            self.pending[b] -= 1
+            if self.pending[b] == 0:
+                lo, hi, _ = self.buckets[b]
+                self.handles.append(dist.all_reduce(self.opt.flat_grad[lo:hi], group=self.group, async_op=True))
+        return hook
+
+    def finish(self):
+        """Call after backward: launch whatever did not fire (unused parameters), wait for all."""
+        for b, left in enumerate(self.pending):
+            if left > 0:
+                lo, hi, _ = self.buckets[b]
+                self.handles.append(dist.all_reduce(self.opt.flat_grad[lo:hi], group=self.group, async_op=True))
+        for h in self.handles:
+            h.wait()
+        self.handles = []
+        self.pending = [b[2] for b in self.buckets]
+
+
+def train_step(model, optimizer, spectrograms, labels, label_lengths, clip_grad_norm=2.0, dp=None,
+               max_label_len=None):
+    """One optimisation step on a featurised batch (train.py:62-87).  Returns the loss tensor
+    (device, no sync)."""
+    optimizer.zero_grad()
+    output = model(spectrograms)                                   # [B, T', V]
+    B, Tp, _ = output.shape
+    # train.py:72-74: every utterance is scored over all T' (padded) encoder frames
+    input_lengths = torch.full((B,), Tp, dtype=torch.int32, device=output.device)
+    loss = ops.ctc_loss(output.float(), labels, input_lengths, label_lengths, blank=0,
+                        max_label_len=max_label_len)
+    loss.backward()
+    world = 1
+    if dp is not None:
+        dp.finish()
+        world = dp.world
+    optimizer.step(max_norm=clip_grad_norm, grad_div=float(world))
+    return loss.detach()
+
+
+def train(batch_size, model, train_loader, optimizer, scheduler, epoch, iter_meter, clip_grad_norm,
+          dp=None, max_steps=None, log=print):
+    model.train()
+    data_len = len(train_loader.dataset) if hasattr(train_loader, "dataset") else len(train_loader)
+    start = batch_start = time.time()
+    for batch_idx, batch in enumerate(train_loader):
+        spectrograms, labels, label_lengths = batch
+        spectrograms = spectrograms.cuda()
+        loss = train_step(model, optimizer, spectrograms, labels.cuda(), label_lengths.cuda(),
+                          clip_grad_norm, dp)
+        scheduler.step()
+        iter_meter.step()
+        if batch_idx % 100 == 0:
+            t100 = round(time.time() - batch_start, 1)
+            log("Train Epoch: {} [{}/{} ({:.0f}%)]\tLoss: {:.6f}\tT100B: {}".format(
+                epoch, batch_idx, data_len, 100.0 * batch_idx / max(1, data_len), loss.item(), t100))
+            batch_start = time.time()
+        if max_steps is not None and batch_idx + 1 >= max_steps:
+            break
+    return round(time.time() - start)
+
+
+@torch.no_grad()
+def eval_dataset(model, loader, name, log=print):
+    """train.py:105-144: mean loss, unweighted mean of per-utterance CER / WER."""
+    model.eval()
+    eval_loss, eval_cer, eval_wer, n = 0.0, [], [], 0
+    for batch in loader:
+        spectrograms, labels, label_lengths = batch
+        spectrograms, labels, label_lengths = spectrograms.cuda(), labels.cuda(), label_lengths.cuda()
+        output = model(spectrograms).float()
+        B, Tp, _ = output.shape
+        input_lengths = torch.full((B,), Tp, dtype=torch.int32, device=output.device)
+        loss, _, _ = ops.ctc_fwd_bwd(output, labels, input_lengths, label_lengths, want_grad=False)
+        eval_loss += float(loss)
+        n += 1
+        preds, targets = decoder.greedy_decoder(output, labels, label_lengths)
+        for tgt, pred in zip(targets, preds):
+            eval_cer.append(decoder.cer(tgt, pred))
+            eval_wer.append(decoder.wer(tgt, pred))
+    avg_cer = sum(eval_cer) / len(eval_cer)
+    avg_wer = sum(eval_wer) / len(eval_wer)
+    log("{}: Average loss: {:.4f}, Average CER: {:4f} Average WER: {:.4f}\n".format(
+        name, eval_loss / max(1, n), avg_cer, avg_wer))
+    return avg_cer
+
+
+def save_checkpoint(path, epoch, model, optimizer):
+    """train.py:171-178 key names."""
+    torch.save({"epoch": epoch, "model_state_dict": model.state_dict(),
+                "optimizer_state_dict": optimizer.state_dict()}, path)
+
+
+def setup_distributed():
+    """One process per GPU; RANK/LOCAL_RANK/WORLD_SIZE from the launcher."""
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if torch.cuda.is_available():
+        torch.cuda.set_device(local)
+    if world > 1 and not dist.is_initialized():
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl" if torch.cuda.is_available() else "gloo")
+    return int(os.environ.get("RANK", "0")), world
+
+
+def main(hparams):
+    rank, world = setup_distributed()
+    torch.manual_seed(7 + rank)
+    log = print if rank == 0 else (lambda *a, **k: None)
+    dtype = {"bf16": torch.bfloat16, "fp32": torch.float32}[hparams["dtype"]]
+    model = net.SRModel(hparams["n_rnn_layers"], hparams["rnn_dim"], hparams["n_vocab"], hparams["n_feats"],
+                        hparams["dropout"], hparams["projection_size"], compute_dtype=dtype).cuda()
+    log("Num Model Parameters", sum(p.nelement() for p in model.parameters()))
+    optimizer = FlatAdam(model.parameters(), lr=hparams["learning_rate"], weight_decay=hparams["weight_decay"])
+    dp = BucketedAllReduce(optimizer) if world > 1 else None
+
+    if not hparams["synthetic"]:
+        raise SystemExit("only --synthetic data is available in this build: the reference's corpora "
+                         "(/hd1 manifests, data.py:105-157) are not on this machine")
+    bs = hparams["batch_size"]
+    train_set = data.SyntheticSorted(hparams["synthetic_clips"], bs, seed=7)
+    eval_set = data.SyntheticSorted(max(bs, hparams["synthetic_clips"] // 8), bs, seed=11, max_s=6.0)
+    order = list(range(rank, len(train_set), world))
+    train_loader = [data.collate_fn(train_set[i], "train") for i in order[: hparams["steps"] or None]]
+    eval_loader = [data.collate_fn(eval_set[i], "valid") for i in range(min(2, len(eval_set)))]
+
+    scheduler = get_linear_schedule_with_warmup(optimizer, 7000 // hparams["multiplier"],
+                                                hparams["epochs"] * len(train_loader))
+    iter_meter, last_cer = IterMeter(), 2.0
+    for epoch in range(1, (1 if hparams["one_iter"] else hparams["epochs"]) + 1):
+        train(bs, model, train_loader, optimizer, scheduler, epoch, iter_meter, hparams["clip_grad_norm"], dp, log=log)
+        if rank == 0:
+            avg_cer = eval_dataset(model, eval_loader, "synthetic", log)
+            if avg_cer < last_cer and hparams["checkpoint"]:
+                save_checkpoint(hparams["checkpoint"], epoch, model, optimizer)
+            last_cer = min(last_cer, avg_cer)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+def parse_args(argv=None):
+    p = argparse.ArgumentParser()
+    p.add_argument("--one_iter", action="store_true")
+    p.add_argument("--datasets", type=str, default="tv-libri")
+    p.add_argument("--multiplier", type=int, default=2)
+    p.add_argument("--device", type=int)
+    p.add_argument("--weight_decay", type=float, default=0.001)
+    p.add_argument("--clip_grad_norm", type=float, default=2.0)
+    p.add_argument("--dropout", type=float, default=0.1)
+    p.add_argument("--learning_rate", type=float, default=3e-4)
+    p.add_argument("--num_epochs", type=int, default=45)
+    p.add_argument("--projection_size", type=int, default=0)
+    # build-side additions
+    p.add_argument("--synthetic", action="store_true")
+    p.add_argument("--synthetic_clips", type=int, default=512)
+    p.add_argument("--steps", type=int, default=0)
+    p.add_argument("--dtype", choices=["bf16", "fp32"], default="bf16")
+    p.add_argument("--checkpoint", type=str, default="")
+    a = p.parse_args(argv)
+    return {
+        "datasets": a.datasets, "multiplier": a.multiplier, "batch_size": 32 * a.multiplier,
+        "epochs": a.num_epochs, "learning_rate": a.learning_rate, "n_rnn_layers": 10, "rnn_dim": 512,
+        "dropout": a.dropout, "n_vocab": 28, "n_feats": data.N_MELS, "weight_decay": a.weight_decay,
+        "clip_grad_norm": a.clip_grad_norm, "one_iter": a.one_iter, "projection_size": a.projection_size,
+        "synthetic": a.synthetic, "synthetic_clips": a.synthetic_clips, "steps": a.steps,
+        "dtype": a.dtype, "checkpoint": a.checkpoint,
+    }
+
+
+if __name__ == "__main__":
+    main(parse_args())

@@ -131,6 +131,55 @@ int sp_adam_step_f32(float* p, const float* g, float* m, float* v, int64_t n, fl
                      float beta2, float eps, float weight_decay, int step, int decoupled,
                      const float* sumsq, float max_norm, float grad_div, void* stream);
 
+/* ---------------------------------------------------------------------------------------
+ * Conv / BatchNorm / ReLU residual stack.  Replaces net.py:9-42, :56-59 (cuDNN Conv2d(1,32,3,s2),
+ * 3 x [Conv2d(32,32,(3,5)) -> BatchNorm2d -> ReLU -> Conv2d -> BatchNorm2d -> += x -> ReLU]).
+ * Activations are channel-last bf16 [B][F][T][32]; N = B*F*T positions.
+ *
+ * sp_conv_pack_w: f32 weight [32][32][3][5] -> bf16 MFMA fragment image (15*2*64*8 elements);
+ *   bwd_data != 0 packs the flipped, channel-transposed weight of the data gradient.
+ * sp_conv3x5: out = conv(tf(in)) (+ bias).  in_mode 0: tf = id; 1: tf = relu(c[0:32]*in + c[32:64])
+ *   (BatchNorm+ReLU of the producer, applied while staging); 2: tf = c[0:32]*in + c[32:64]*in2 +
+ *   c[64:96] (BatchNorm backward from (dz, y)).  Zero padding applies after tf.  epi_mode 0: none
+ *   (forward, bias added); 1: out *= [e[0:32]*epi_src + e[32:64] > 0] (ReLU mask recomputed from
+ *   the pre-BN tensor); 2: out += epi_src (residual gradient).  Supported pairs: (0,0) (1,0) (2,1) (2,2).
+ * sp_conv3x5_wgrad: gw[32][32][3][5] += sum_pos dy[pos][co] * a[pos + tap][ci], with
+ *   a = a_src (a_mode 0) or relu(BN(a_src)) (a_mode 1), dy = g_coef affine of (g, y) as in_mode 2.
+ *   gwp_ws: 15*32*32 f32 scratch (zeroed inside).
+ * sp_conv_stem_fwd/bwd: Conv2d(1,32,3,stride 2,pad 1) on the f32 spectrogram [B][Fin][Tin] ->
+ *   [B][F][T][32], F = (Fin-1)/2+1, T = (Tin-1)/2+1; bwd accumulates gw[32*9], gbias[32].
+ * sp_bn_stats: sums[0:32] = sum y, sums[32:64] = sum y^2 (zeroed inside).
+ * sp_bn_bwd_reduce: sums = (sum g, sum g*y).
+ * sp_bn_finalize_fwd: coef = (scale, shift), save = (mean, invstd); training != 0 uses the batch
+ *   sums and updates running stats (momentum, unbiased variance), else uses running stats.
+ * sp_bn_finalize_bwd: coef3 (in_mode 2 coefficients) from the backward sums; ggamma/gbeta accumulate.
+ * sp_block_out: z = relu(coef-affine(y2) + x); z granule address = b*zsb + f*zsf + t*zst (elements),
+ *   which lets the last block write the [T][B][F*32] layout the SRU stack reads.
+ * sp_block_bwd_in: gpre = gz * [z > 0] (gz, z in that layout); sums = (sum gpre, sum gpre*y2).
+ * --------------------------------------------------------------------------------------- */
+int sp_conv_pack_w(const float* w, int bwd_data, void* wpack, void* stream);
+int sp_conv3x5(const void* in, const void* in2, const float* coef, int in_mode, const void* wpack,
+               const float* bias, const void* epi_src, const float* epi_coef, int epi_mode, int B,
+               int F, int T, void* out, void* stream);
+int sp_conv3x5_wgrad(const void* a_src, const float* a_coef, int a_mode, const void* g,
+                     const void* y, const float* g_coef, int B, int F, int T, float* gwp_ws,
+                     float* gw, void* stream);
+int sp_conv_stem_fwd(const float* spec, const float* w, const float* bias, int B, int Fin, int Tin,
+                     void* out, void* stream);
+int sp_conv_stem_bwd(const float* spec, const void* gout, int B, int Fin, int Tin, float* gw,
+                     float* gbias, void* stream);
+int sp_bn_stats(const void* y, int64_t npos, float* sums, void* stream);
+int sp_bn_bwd_reduce(const void* g, const void* y, int64_t npos, float* sums, void* stream);
+int sp_bn_finalize_fwd(const float* sums, int64_t npos, const float* gamma, const float* beta,
+                       float* rmean, float* rvar, float momentum, float eps, int training,
+                       float* coef, float* save, void* stream);
+int sp_bn_finalize_bwd(const float* sums, const float* save, const float* gamma, int64_t npos,
+                       float* coef3, float* ggamma, float* gbeta, void* stream);
+int sp_block_out(const void* y2, const float* coef, const void* x, int B, int F, int T, void* z,
+                 int64_t zsb, int64_t zsf, int64_t zst, void* stream);
+int sp_block_bwd_in(const void* gz, const void* z, int64_t zsb, int64_t zsf, int64_t zst,
+                    const void* y2, int B, int F, int T, void* gpre, float* sums, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -31,6 +31,17 @@ SIGNATURES = {
                         _vp]),
     "sp_sumsq_f32": (_i, [_vp, _i64, _vp, _vp]),
     "sp_adam_step_f32": (_i, [_vp, _vp, _vp, _vp, _i64, _f, _f, _f, _f, _f, _i, _i, _vp, _f, _f, _vp]),
+    "sp_conv_pack_w": (_i, [_vp, _i, _vp, _vp]),
+    "sp_conv3x5": (_i, [_vp, _vp, _vp, _i, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp, _vp]),
+    "sp_conv3x5_wgrad": (_i, [_vp, _vp, _i, _vp, _vp, _vp, _i, _i, _i, _vp, _vp, _vp]),
+    "sp_conv_stem_fwd": (_i, [_vp, _vp, _vp, _i, _i, _i, _vp, _vp]),
+    "sp_conv_stem_bwd": (_i, [_vp, _vp, _i, _i, _i, _vp, _vp, _vp]),
+    "sp_bn_stats": (_i, [_vp, _i64, _vp, _vp]),
+    "sp_bn_bwd_reduce": (_i, [_vp, _vp, _i64, _vp, _vp]),
+    "sp_bn_finalize_fwd": (_i, [_vp, _i64, _vp, _vp, _vp, _vp, _f, _f, _i, _vp, _vp, _vp]),
+    "sp_bn_finalize_bwd": (_i, [_vp, _vp, _vp, _i64, _vp, _vp, _vp, _vp]),
+    "sp_block_out": (_i, [_vp, _vp, _vp, _i, _i, _i, _vp, _i64, _i64, _i64, _vp]),
+    "sp_block_bwd_in": (_i, [_vp, _vp, _i64, _i64, _i64, _vp, _i, _i, _i, _vp, _vp, _vp]),
 }
 
 _lib = None

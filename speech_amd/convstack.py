@@ -1,0 +1,154 @@
+"""Conv / BatchNorm / ReLU residual stack of SRModel (net.py:56-59 and :6-42 of the reference) on
+the hand-written channel-last bf16 kernels of csrc/conv.hip, forward and backward.
+
+The stack takes the f32 spectrogram [B,1,n_feats,T] and returns the SRU input directly in
+[T', B, F*32] layout with feature index f*32 + c (the reference's reshape at net.py:81-83 gives
+c*F + f; SRModel permutes the first SRU layer's weight rows and layer-norm vectors to match, the
+state_dict keeps the reference order).  BatchNorm is never materialised: the consumer convolution
+applies scale/shift(+ReLU) while it stages its input, and the backward convolutions apply the
+BatchNorm-backward affine map the same way.
+"""
+import torch
+
+from ._lib import check, lib, ptr, stream_ptr
+
+IN_ID, IN_BNRELU, IN_BNBWD = 0, 1, 2
+EPI_NONE, EPI_MASK, EPI_ADD = 0, 1, 2
+C = 32
+PACK_ELEMS = 15 * 2 * 64 * 8
+
+
+def _f32(t):
+    return t.detach().float().contiguous()
+
+
+def _pack(w, bwd_data):
+    out = torch.empty(PACK_ELEMS, dtype=torch.bfloat16, device=w.device)
+    check(lib().sp_conv_pack_w(ptr(w), int(bwd_data), ptr(out), stream_ptr()), "sp_conv_pack_w")
+    return out
+
+
+def _conv(inp, in2, coef, in_mode, wpack, bias, epi_src, epi_coef, epi_mode, B, F, T):
+    out = torch.empty((B, F, T, C), dtype=torch.bfloat16, device=inp.device)
+    check(lib().sp_conv3x5(ptr(inp), ptr(in2), ptr(coef), in_mode, ptr(wpack), ptr(bias), ptr(epi_src),
+                           ptr(epi_coef), epi_mode, B, F, T, ptr(out), stream_ptr()), "sp_conv3x5")
+    return out
+
+
+def _bn_fwd(y, npos, bn_w, bn_b, rmean, rvar, momentum, eps, training):
+    dev = y.device
+    coef = torch.empty(64, dtype=torch.float32, device=dev)
+    save = torch.empty(64, dtype=torch.float32, device=dev)
+    sums = None
+    if training:
+        sums = torch.empty(64, dtype=torch.float32, device=dev)
+        check(lib().sp_bn_stats(ptr(y), npos, ptr(sums), stream_ptr()), "sp_bn_stats")
+    check(lib().sp_bn_finalize_fwd(ptr(sums), npos, ptr(bn_w), ptr(bn_b), ptr(rmean), ptr(rvar), momentum,
+                                   eps, int(training), ptr(coef), ptr(save), stream_ptr()), "sp_bn_finalize_fwd")
+    return coef, save
+
+
+class _ConvStackFn(torch.autograd.Function):
+    """args: spec, training, momentum, eps, stem_w, stem_b, then per block
+    (conv1.w, conv1.b, bn1.w, bn1.b, conv2.w, conv2.b, bn2.w, bn2.b), then per block the four
+    running-stat buffers (bn1.mean, bn1.var, bn2.mean, bn2.var)."""
+
+    @staticmethod
+    def forward(ctx, spec, training, momentum, eps, stem_w, stem_b, *rest):
+        nblk = len(rest) // 12
+        params, bufs = rest[: 8 * nblk], rest[8 * nblk:]
+        spec = spec.detach().float().contiguous()
+        B, _, Fin, Tin = spec.shape
+        F, T = (Fin - 1) // 2 + 1, (Tin - 1) // 2 + 1
+        npos = B * F * T
+        dev = spec.device
+        with torch.cuda.device(dev):
+            s = stream_ptr()
+            sw, sb = _f32(stem_w), _f32(stem_b)
+            x = torch.empty((B, F, T, C), dtype=torch.bfloat16, device=dev)
+            check(lib().sp_conv_stem_fwd(ptr(spec), ptr(sw), ptr(sb), B, Fin, Tin, ptr(x), s), "sp_conv_stem_fwd")
+            saved = []
+            for i in range(nblk):
+                c1w, c1b, b1w, b1b, c2w, c2b, b2w, b2b = [_f32(p) for p in params[8 * i: 8 * i + 8]]
+                rm1, rv1, rm2, rv2 = bufs[4 * i: 4 * i + 4]
+                y1 = _conv(x, None, None, IN_ID, _pack(c1w, 0), c1b, None, None, EPI_NONE, B, F, T)
+                coef1, save1 = _bn_fwd(y1, npos, b1w, b1b, rm1, rv1, momentum, eps, training)
+                y2 = _conv(y1, None, coef1, IN_BNRELU, _pack(c2w, 0), c2b, None, None, EPI_NONE, B, F, T)
+                coef2, save2 = _bn_fwd(y2, npos, b2w, b2b, rm2, rv2, momentum, eps, training)
+                last = i == nblk - 1
+                if last:   # [T][B][F*32]
+                    z = torch.empty((T, B, F * C), dtype=torch.bfloat16, device=dev)
+                    zs = (F * C, C, B * F * C)
+                else:      # [B][F][T][32]
+                    z = torch.empty((B, F, T, C), dtype=torch.bfloat16, device=dev)
+                    zs = (F * T * C, T * C, C)
+                check(lib().sp_block_out(ptr(y2), ptr(coef2), ptr(x), B, F, T, ptr(z), zs[0], zs[1], zs[2], s),
+                      "sp_block_out")
+                saved.append((x, y1, y2, z, zs, coef1, save1, save2, c1w, c2w, b1w, b2w))
+                x = z
+        ctx.saved = saved
+        ctx.spec = spec
+        ctx.dims = (B, Fin, Tin, F, T, nblk)
+        ctx.training = training
+        return x
+
+    @staticmethod
+    def backward(ctx, gout):
+        if not ctx.training:
+            raise RuntimeError("conv stack backward needs training mode (batch-statistics BatchNorm)")
+        B, Fin, Tin, F, T, nblk = ctx.dims
+        npos = B * F * T
+        dev = gout.device
+        gz = gout.contiguous()
+        if gz.dtype != torch.bfloat16:
+            gz = gz.to(torch.bfloat16)
+        grads = []
+        with torch.cuda.device(dev):
+            s = stream_ptr()
+            ws = torch.empty(15 * 32 * 32, dtype=torch.float32, device=dev)
+            for i in range(nblk - 1, -1, -1):
+                x, y1, y2, z, zs, coef1, save1, save2, c1w, c2w, b1w, b2w = ctx.saved[i]
+                z32 = lambda: torch.zeros(32, dtype=torch.float32, device=dev)  # noqa: E731
+                gg1, gb1, gg2, gb2 = z32(), z32(), z32(), z32()
+                gw1, gw2 = torch.zeros_like(c1w), torch.zeros_like(c2w)
+                sums = torch.empty(64, dtype=torch.float32, device=dev)
+                c3_2 = torch.empty(96, dtype=torch.float32, device=dev)
+                c3_1 = torch.empty(96, dtype=torch.float32, device=dev)
+                g2pre = torch.empty((B, F, T, C), dtype=torch.bfloat16, device=dev)
+                check(lib().sp_block_bwd_in(ptr(gz), ptr(z), zs[0], zs[1], zs[2], ptr(y2), B, F, T, ptr(g2pre),
+                                            ptr(sums), s), "sp_block_bwd_in")
+                check(lib().sp_bn_finalize_bwd(ptr(sums), ptr(save2), ptr(b2w), npos, ptr(c3_2), ptr(gg2),
+                                               ptr(gb2), s), "sp_bn_finalize_bwd")
+                g1pre = _conv(g2pre, y2, c3_2, IN_BNBWD, _pack(c2w, 1), None, y1, coef1, EPI_MASK, B, F, T)
+                check(lib().sp_conv3x5_wgrad(ptr(y1), ptr(coef1), IN_BNRELU, ptr(g2pre), ptr(y2), ptr(c3_2),
+                                             B, F, T, ptr(ws), ptr(gw2), s), "sp_conv3x5_wgrad")
+                check(lib().sp_bn_bwd_reduce(ptr(g1pre), ptr(y1), npos, ptr(sums), s), "sp_bn_bwd_reduce")
+                check(lib().sp_bn_finalize_bwd(ptr(sums), ptr(save1), ptr(b1w), npos, ptr(c3_1), ptr(gg1),
+                                               ptr(gb1), s), "sp_bn_finalize_bwd")
+                gx = _conv(g1pre, y1, c3_1, IN_BNBWD, _pack(c1w, 1), None, g2pre, None, EPI_ADD, B, F, T)
+                check(lib().sp_conv3x5_wgrad(ptr(x), None, IN_ID, ptr(g1pre), ptr(y1), ptr(c3_1), B, F, T,
+                                             ptr(ws), ptr(gw1), s), "sp_conv3x5_wgrad")
+                # a conv bias feeding batch-statistics BatchNorm has an identically zero gradient
+                grads = [gw1, z32(), gg1, gb1, gw2, z32(), gg2, gb2] + grads
+                gz = gx
+            gsw = torch.zeros(32 * 9, dtype=torch.float32, device=dev)
+            gsb = torch.zeros(32, dtype=torch.float32, device=dev)
+            check(lib().sp_conv_stem_bwd(ptr(ctx.spec), ptr(gz), B, Fin, Tin, ptr(gsw), ptr(gsb), s),
+                  "sp_conv_stem_bwd")
+        ctx.saved = None
+        return (None, None, None, None, gsw.view(32, 1, 3, 3), gsb, *grads, *([None] * (4 * nblk)))
+
+
+def conv_stack(spec, cnn, blocks, training):
+    """cnn: nn.Conv2d(1,32,3,stride 2); blocks: iterable of ResidualBlock modules."""
+    params, bufs = [], []
+    for blk in blocks:
+        params += [blk.conv1.weight, blk.conv1.bias, blk.bn1.weight, blk.bn1.bias,
+                   blk.conv2.weight, blk.conv2.bias, blk.bn2.weight, blk.bn2.bias]
+        bufs += [blk.bn1.running_mean, blk.bn1.running_var, blk.bn2.running_mean, blk.bn2.running_var]
+        if training:
+            blk.bn1.num_batches_tracked += 1
+            blk.bn2.num_batches_tracked += 1
+    bn = blocks[0].bn1
+    return _ConvStackFn.apply(spec, bool(training), float(bn.momentum), float(bn.eps), cnn.weight, cnn.bias,
+                              *params, *bufs)

@@ -1,0 +1,717 @@
+// Conv / BatchNorm / ReLU residual stack of the encoder for gfx950, forward and backward.
+// Replaces net.py:9-42 and :56-59 of the reference (cuDNN Conv2d + BatchNorm2d + ReLU, NCHW) with
+// channel-last bf16 kernels: activations are [B][F][T][32] (64 bytes per position), so that one
+// position's 32 channels are one MFMA K/N fragment row and every access is a 16-byte chunk.
+//
+//   conv3x5_kernel      3x5 convolution 32->32 as an implicit GEMM on v_mfma_f32_32x32x16_bf16:
+//                       M = 32 output channels (A = weights, held in 120 VGPRs for the whole
+//                       kernel), N = 32 positions, K = 16 input channels of one tap; 30 MFMAs per
+//                       32 positions.  The input strip (6 rows x 68 positions) is staged once
+//                       through registers into LDS with the producer's BatchNorm(+ReLU) -- or the
+//                       BatchNorm-backward affine map -- applied on the way, so normalised
+//                       activations are never materialised.  Same kernel does backward-data
+//                       (flipped/transposed weight pack) with a ReLU-mask or residual-add epilogue.
+//   conv3x5_wgrad_kernel weight gradient: contraction over positions (K), operands transposed into
+//                       LDS ([channel][position]); 5 waves = 5 kw taps, each holds 3 kh
+//                       accumulators; a 3-row ring of the activation, 5 shifted copies of dy.
+//   stem kernels        1->32 3x3 stride-2 convolution on the f32 spectrogram (VALU; K = 9).
+//   bn_* / block_*      per-channel statistics, finalisation to affine coefficients, the block's
+//                       residual output z = relu(bn2(y2) + x) and its backward entry.
+// LDS rows are padded (80-byte positions, 144-byte channel rows) so every ds_read_b128 group hits
+// 16 distinct 16-byte slots.
+#include "common.h"
+
+namespace sp {
+
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+constexpr int kC = 32;
+
+__device__ __forceinline__ void unpack8(const uint4& v, float (&f)[8]) {
+    const uint32_t w[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        f[2 * i] = __uint_as_float(w[i] << 16);
+        f[2 * i + 1] = __uint_as_float(w[i] & 0xFFFF0000u);
+    }
+}
+__device__ __forceinline__ uint32_t bf16_bits(float x) {
+    return (uint32_t)__builtin_bit_cast(unsigned short, __float2bfloat16(x));
+}
+__device__ __forceinline__ uint4 pack8(const float (&f)[8]) {
+    uint4 v;
+    v.x = bf16_bits(f[0]) | (bf16_bits(f[1]) << 16);
+    v.y = bf16_bits(f[2]) | (bf16_bits(f[3]) << 16);
+    v.z = bf16_bits(f[4]) | (bf16_bits(f[5]) << 16);
+    v.w = bf16_bits(f[6]) | (bf16_bits(f[7]) << 16);
+    return v;
+}
+__device__ __forceinline__ uint2 pack4(float a, float b, float c, float d) {
+    uint2 v;
+    v.x = bf16_bits(a) | (bf16_bits(b) << 16);
+    v.y = bf16_bits(c) | (bf16_bits(d) << 16);
+    return v;
+}
+
+enum { IN_ID = 0, IN_BNRELU = 1, IN_BNBWD = 2 };
+enum { EPI_NONE = 0, EPI_MASK = 1, EPI_ADD = 2 };
+
+// ---------------------------------------------------------------------------------------------
+// weight pack: wpack[(tap*2+half)*64 + lane][8], lane (r = lane&31, h = lane>>5), element j =
+// Weff[out = r][in = 16 half + 8 h + j][tap].  bwd_data: Weff[ci][co][kh][kw] = w[co][ci][2-kh][4-kw].
+// ---------------------------------------------------------------------------------------------
+__global__ void conv_pack_kernel(const float* __restrict__ w, int bwd_data, __hip_bfloat16* __restrict__ wpack) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= 15 * 2 * 64 * 8) return;
+    const int j = i & 7, lane = (i >> 3) & 63, half = (i >> 9) & 1, tap = i >> 10;
+    const int r = lane & 31, h = lane >> 5;
+    const int kin = 16 * half + 8 * h + j;
+    const int kh = tap / 5, kw = tap % 5;
+    float v;
+    if (!bwd_data) v = w[((r * 32 + kin) * 3 + kh) * 5 + kw];
+    else v = w[((kin * 32 + r) * 3 + (2 - kh)) * 5 + (4 - kw)];
+    wpack[i] = __float2bfloat16(v);
+}
+
+// ---------------------------------------------------------------------------------------------
+// conv3x5 (forward / backward-data)
+// ---------------------------------------------------------------------------------------------
+constexpr int kTP = 64, kFR = 4, kPW = kTP + 4, kRows = kFR + 2, kPStr = 40;  // bf16 elems / position
+
+template <int IN_MODE, int EPI>
+__global__ __launch_bounds__(256, 2) void conv3x5_kernel(
+    const __hip_bfloat16* __restrict__ in, const __hip_bfloat16* __restrict__ in2,
+    const float* __restrict__ coef, const __hip_bfloat16* __restrict__ wpack,
+    const float* __restrict__ bias, const __hip_bfloat16* __restrict__ epi_src,
+    const float* __restrict__ epi_coef, int B, int F, int T, __hip_bfloat16* __restrict__ out) {
+    __shared__ __attribute__((aligned(16))) __hip_bfloat16 tile[kRows * kPW * kPStr];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int r = lane & 31, h = lane >> 5;
+    const int t0 = blockIdx.x * kTP, f0 = blockIdx.y * kFR, b = blockIdx.z;
+    const int64_t img = (int64_t)b * F * T;
+
+    // ---- stage the input strip (transform on the way) ----
+    {
+        const int ch4 = tid & 3;
+        float c0[8], c1[8], c2[8];
+        if (IN_MODE != IN_ID) {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                c0[j] = coef[ch4 * 8 + j];
+                c1[j] = coef[32 + ch4 * 8 + j];
+                c2[j] = (IN_MODE == IN_BNBWD) ? coef[64 + ch4 * 8 + j] : 0.f;
+            }
+        }
+#pragma unroll 1
+        for (int id = tid; id < kRows * kPW * 4; id += 256) {
+            const int row = id / (kPW * 4);
+            const int pos = (id - row * (kPW * 4)) >> 2;
+            const int f = f0 - 1 + row, t = t0 - 2 + pos;
+            uint4 v = make_uint4(0, 0, 0, 0);
+            if (f >= 0 && f < F && t >= 0 && t < T) {
+                const int64_t off = ((img + (int64_t)f * T + t) * kC + ch4 * 8);
+                v = *reinterpret_cast<const uint4*>(in + off);
+                if (IN_MODE == IN_BNRELU) {
+                    float x[8];
+                    unpack8(v, x);
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) x[j] = fmaxf(0.f, c0[j] * x[j] + c1[j]);
+                    v = pack8(x);
+                } else if (IN_MODE == IN_BNBWD) {
+                    const uint4 v2 = *reinterpret_cast<const uint4*>(in2 + off);
+                    float x[8], y[8];
+                    unpack8(v, x);
+                    unpack8(v2, y);
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) x[j] = c0[j] * x[j] + c1[j] * y[j] + c2[j];
+                    v = pack8(x);
+                }
+            }
+            *reinterpret_cast<uint4*>(tile + (row * kPW + pos) * kPStr + ch4 * 8) = v;
+        }
+    }
+    // ---- weights: the whole 32x480 matrix in registers (30 fragments) ----
+    bf16x8 wreg[30];
+#pragma unroll
+    for (int i = 0; i < 30; ++i)
+        wreg[i] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const uint4*>(wpack + ((int64_t)i * 64 + lane) * 8));
+    __syncthreads();
+
+    const int f = f0 + wave;
+    f32x16 acc[2];
+#pragma unroll
+    for (int m = 0; m < 2; ++m)
+#pragma unroll
+        for (int q = 0; q < 16; ++q)
+            acc[m][q] = (EPI == EPI_NONE && bias) ? bias[8 * (q >> 2) + 4 * h + (q & 3)] : 0.f;
+
+#pragma unroll
+    for (int kh = 0; kh < 3; ++kh) {
+#pragma unroll
+        for (int kw = 0; kw < 5; ++kw) {
+#pragma unroll
+            for (int half = 0; half < 2; ++half) {
+#pragma unroll
+                for (int m = 0; m < 2; ++m) {
+                    const __hip_bfloat16* p = tile + ((wave + kh) * kPW + m * 32 + r + kw) * kPStr + (half * 2 + h) * 8;
+                    const bf16x8 bfrag = __builtin_bit_cast(bf16x8, *reinterpret_cast<const uint4*>(p));
+                    acc[m] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wreg[(kh * 5 + kw) * 2 + half], bfrag, acc[m], 0, 0, 0);
+                }
+            }
+        }
+    }
+    if (f >= F) return;
+    // ---- epilogue: lane = position (column), registers = output channels 8g + 4h + i ----
+#pragma unroll
+    for (int m = 0; m < 2; ++m) {
+        const int t = t0 + m * 32 + r;
+        if (t >= T) continue;
+        const int64_t base = (img + (int64_t)f * T + t) * kC;
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            const int co = 8 * g + 4 * h;
+            float v[4] = {acc[m][4 * g], acc[m][4 * g + 1], acc[m][4 * g + 2], acc[m][4 * g + 3]};
+            if (EPI != EPI_NONE) {
+                const uint2 e = *reinterpret_cast<const uint2*>(epi_src + base + co);
+                const float e4[4] = {__uint_as_float(e.x << 16), __uint_as_float(e.x & 0xFFFF0000u),
+                                     __uint_as_float(e.y << 16), __uint_as_float(e.y & 0xFFFF0000u)};
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    if (EPI == EPI_MASK) {
+                        const bool keep = epi_coef[co + i] * e4[i] + epi_coef[32 + co + i] > 0.f;
+                        v[i] = keep ? v[i] : 0.f;
+                    } else {
+                        v[i] += e4[i];
+                    }
+                }
+            }
+            *reinterpret_cast<uint2*>(out + base + co) = pack4(v[0], v[1], v[2], v[3]);
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// conv3x5 weight gradient
+// ---------------------------------------------------------------------------------------------
+constexpr int kWR = 72;  // padded row (positions) of the transposed LDS images, 144 bytes
+
+template <int A_MODE>
+__global__ __launch_bounds__(320) void conv3x5_wgrad_kernel(
+    const __hip_bfloat16* __restrict__ asrc, const float* __restrict__ acoef,
+    const __hip_bfloat16* __restrict__ g, const __hip_bfloat16* __restrict__ y,
+    const float* __restrict__ gcoef, int B, int F, int T, int fsplit, float* __restrict__ gwp) {
+    __shared__ __attribute__((aligned(16))) __hip_bfloat16 gys[5 * 32 * kWR];
+    __shared__ __attribute__((aligned(16))) __hip_bfloat16 aring[3 * 32 * kWR];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int r = lane & 31, h = lane >> 5;
+    const int t0 = blockIdx.x * 64;
+    const int b = blockIdx.y / fsplit, fs = blockIdx.y % fsplit;
+    const int fper = (F + fsplit - 1) / fsplit;
+    const int fa = fs * fper, fb = min(F, fa + fper);
+    const int64_t img = (int64_t)b * F * T;
+    const int ch4 = tid & 3;
+
+    float ga[8], gb[8], gd[8], a0[8], a1[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        ga[j] = gcoef[ch4 * 8 + j];
+        gb[j] = gcoef[32 + ch4 * 8 + j];
+        gd[j] = gcoef[64 + ch4 * 8 + j];
+        a0[j] = (A_MODE == IN_BNRELU) ? acoef[ch4 * 8 + j] : 1.f;
+        a1[j] = (A_MODE == IN_BNRELU) ? acoef[32 + ch4 * 8 + j] : 0.f;
+    }
+
+    auto stage_a = [&](int frow) {  // activation row frow -> ring slot (frow + 3) % 3, [ci][pos]
+        if (tid < 256) {
+            const int pos = tid >> 2, t = t0 + pos;
+            float x[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+            if (frow >= 0 && frow < F && t < T) {
+                const uint4 v = *reinterpret_cast<const uint4*>(asrc + (img + (int64_t)frow * T + t) * kC + ch4 * 8);
+                unpack8(v, x);
+                if (A_MODE == IN_BNRELU) {
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) x[j] = fmaxf(0.f, a0[j] * x[j] + a1[j]);
+                }
+            }
+            __hip_bfloat16* dst = aring + ((frow + 3) % 3) * 32 * kWR + (ch4 * 8) * kWR + pos;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) dst[j * kWR] = __float2bfloat16(x[j]);
+        }
+    };
+    auto stage_g = [&](int frow) {  // dy row (BN-backward affine applied) -> 5 shifted copies [co][pos]
+        if (tid < 272) {
+            const int idx = tid >> 2, t = t0 - 2 + idx;
+            float x[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+            if (t >= 0 && t < T) {
+                const int64_t off = (img + (int64_t)frow * T + t) * kC + ch4 * 8;
+                float yv[8];
+                unpack8(*reinterpret_cast<const uint4*>(g + off), x);
+                unpack8(*reinterpret_cast<const uint4*>(y + off), yv);
+#pragma unroll
+                for (int j = 0; j < 8; ++j) x[j] = ga[j] * x[j] + gb[j] * yv[j] + gd[j];
+            }
+            __hip_bfloat16 xb[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) xb[j] = __float2bfloat16(x[j]);
+#pragma unroll
+            for (int s = 0; s < 5; ++s) {
+                const int i = idx + s - 4;  // copy s holds dy[t0 + i - s + 2] at column i
+                if (i >= 0 && i < 64) {
+                    __hip_bfloat16* dst = gys + (s * 32 + ch4 * 8) * kWR + i;
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) dst[j * kWR] = xb[j];
+                }
+            }
+        }
+    };
+
+    f32x16 acc[3];
+#pragma unroll
+    for (int k = 0; k < 3; ++k)
+#pragma unroll
+        for (int q = 0; q < 16; ++q) acc[k][q] = 0.f;
+
+    stage_a(fa - 1);
+    stage_a(fa);
+    for (int f = fa; f < fb; ++f) {
+        stage_a(f + 1);
+        stage_g(f);
+        __syncthreads();
+        const int kw = wave;
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) {
+            const bf16x8 A = __builtin_bit_cast(
+                bf16x8, *reinterpret_cast<const uint4*>(gys + (kw * 32 + r) * kWR + ks * 16 + 8 * h));
+#pragma unroll
+            for (int kh = 0; kh < 3; ++kh) {
+                const int slot = (f + kh + 2) % 3;  // row f + kh - 1
+                const bf16x8 Bv = __builtin_bit_cast(
+                    bf16x8, *reinterpret_cast<const uint4*>(aring + (slot * 32 + r) * kWR + ks * 16 + 8 * h));
+                acc[kh] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A, Bv, acc[kh], 0, 0, 0);
+            }
+        }
+        __syncthreads();
+    }
+    // D[row = co][col = ci]: lane = ci, registers = co 8g + 4h + i; gwp[tap][co][ci]
+#pragma unroll
+    for (int kh = 0; kh < 3; ++kh) {
+        const int tap = kh * 5 + wave;
+#pragma unroll
+        for (int q = 0; q < 16; ++q) {
+            const int co = 8 * (q >> 2) + 4 * h + (q & 3);
+            atomicAdd(gwp + (tap * 32 + co) * 32 + r, acc[kh][q]);
+        }
+    }
+}
+
+__global__ void conv_wgrad_unpack_kernel(const float* __restrict__ gwp, float* __restrict__ gw) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;  // over [co][ci][kh][kw]
+    if (i >= 32 * 32 * 15) return;
+    const int tap = i % 15, ci = (i / 15) % 32, co = i / (15 * 32);
+    gw[i] += gwp[(tap * 32 + co) * 32 + ci];
+}
+
+// ---------------------------------------------------------------------------------------------
+// stem: Conv2d(1, 32, 3, stride 2, pad 1) on the f32 spectrogram [B][Fin][Tin]
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void stem_fwd_kernel(const float* __restrict__ spec,
+                                                       const float* __restrict__ w,
+                                                       const float* __restrict__ bias, int B, int Fin,
+                                                       int Tin, int F, int T,
+                                                       __hip_bfloat16* __restrict__ out) {
+    __shared__ __attribute__((aligned(16))) float sw[9 * 32 + 32];  // [tap][co], then bias
+    for (int i = threadIdx.x; i < 288; i += 256) sw[(i % 9) * 32 + i / 9] = w[i];  // w is [co][9]
+    if (threadIdx.x < 32) sw[288 + threadIdx.x] = bias[threadIdx.x];
+    __syncthreads();
+    const int64_t n = (int64_t)B * F * T;
+    for (int64_t p = (int64_t)blockIdx.x * 256 + threadIdx.x; p < n; p += (int64_t)gridDim.x * 256) {
+        const int t = (int)(p % T);
+        const int64_t bf = p / T;
+        const int f = (int)(bf % F), b = (int)(bf / F);
+        float x[9];
+#pragma unroll
+        for (int kh = 0; kh < 3; ++kh)
+#pragma unroll
+            for (int kw = 0; kw < 3; ++kw) {
+                const int fi = 2 * f - 1 + kh, ti = 2 * t - 1 + kw;
+                x[kh * 3 + kw] = (fi >= 0 && fi < Fin && ti >= 0 && ti < Tin)
+                                     ? spec[((int64_t)b * Fin + fi) * Tin + ti] : 0.f;
+            }
+#pragma unroll
+        for (int c8 = 0; c8 < 4; ++c8) {
+            float o[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) o[j] = sw[288 + c8 * 8 + j];
+#pragma unroll
+            for (int tap = 0; tap < 9; ++tap)
+#pragma unroll
+                for (int j = 0; j < 8; ++j) o[j] += sw[tap * 32 + c8 * 8 + j] * x[tap];
+            *reinterpret_cast<uint4*>(out + p * kC + c8 * 8) = pack8(o);
+        }
+    }
+}
+
+// shuffle-reduce NV values over the 16 lanes of a wave that share (lane & 3)
+template <int NV>
+__device__ __forceinline__ void reduce_ch4(float (&v)[NV]) {
+#pragma unroll
+    for (int o = 4; o < 64; o <<= 1)
+#pragma unroll
+        for (int i = 0; i < NV; ++i) v[i] += __shfl_xor(v[i], o);
+}
+
+// each thread owns one 16-byte chunk (8 channels, group tid & 3) of a position
+__global__ __launch_bounds__(256) void stem_bwd_kernel(const float* __restrict__ spec,
+                                                       const __hip_bfloat16* __restrict__ gout, int B,
+                                                       int Fin, int Tin, int F, int T,
+                                                       float* __restrict__ gw, float* __restrict__ gbias) {
+    __shared__ float red[4][4][80];
+    const int ch4 = threadIdx.x & 3;
+    float acc[80];
+#pragma unroll
+    for (int i = 0; i < 80; ++i) acc[i] = 0.f;
+    const int64_t n = (int64_t)B * F * T;
+    for (int64_t p = ((int64_t)blockIdx.x * 256 + threadIdx.x) >> 2; p < n; p += ((int64_t)gridDim.x * 256) >> 2) {
+        const int t = (int)(p % T);
+        const int64_t bf = p / T;
+        const int f = (int)(bf % F), b = (int)(bf / F);
+        float gch[8];
+        unpack8(*reinterpret_cast<const uint4*>(gout + p * kC + ch4 * 8), gch);
+#pragma unroll
+        for (int kh = 0; kh < 3; ++kh)
+#pragma unroll
+            for (int kw = 0; kw < 3; ++kw) {
+                const int fi = 2 * f - 1 + kh, ti = 2 * t - 1 + kw;
+                const float x = (fi >= 0 && fi < Fin && ti >= 0 && ti < Tin)
+                                    ? spec[((int64_t)b * Fin + fi) * Tin + ti] : 0.f;
+#pragma unroll
+                for (int j = 0; j < 8; ++j) acc[j * 9 + kh * 3 + kw] += gch[j] * x;
+            }
+#pragma unroll
+        for (int j = 0; j < 8; ++j) acc[72 + j] += gch[j];
+    }
+    reduce_ch4<80>(acc);
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    if (lane < 4) {
+#pragma unroll
+        for (int i = 0; i < 80; ++i) red[wave][lane][i] = acc[i];
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < 320; i += 256) {
+        const int c4 = i / 80, k = i % 80;
+        const float s = red[0][c4][k] + red[1][c4][k] + red[2][c4][k] + red[3][c4][k];
+        if (k < 72) atomicAdd(gw + (c4 * 8 + k / 9) * 9 + k % 9, s);
+        else atomicAdd(gbias + c4 * 8 + (k - 72), s);
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// BatchNorm statistics / finalisation, block output and backward entry
+// ---------------------------------------------------------------------------------------------
+// sums[0..31] += sum_pos a*b', sums[32..63] += sum_pos second moment, per channel:
+//   MODE 0 (forward stats):   (sum y, sum y^2)
+//   MODE 1 (backward reduce): (sum g, sum g*y)
+template <int MODE>
+__global__ __launch_bounds__(256) void bn_reduce_kernel(const __hip_bfloat16* __restrict__ p0,
+                                                        const __hip_bfloat16* __restrict__ p1, int64_t n,
+                                                        float* __restrict__ sums) {
+    __shared__ float red[4][4][16];
+    const int ch4 = threadIdx.x & 3;
+    float acc[16];
+#pragma unroll
+    for (int i = 0; i < 16; ++i) acc[i] = 0.f;
+    for (int64_t c = (int64_t)blockIdx.x * 256 + threadIdx.x; c < n * 4; c += (int64_t)gridDim.x * 256) {
+        float a[8], bv[8];
+        unpack8(*reinterpret_cast<const uint4*>(p0 + c * 8), a);
+        if (MODE == 1) unpack8(*reinterpret_cast<const uint4*>(p1 + c * 8), bv);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            acc[j] += a[j];
+            acc[8 + j] += (MODE == 0) ? a[j] * a[j] : a[j] * bv[j];
+        }
+    }
+    reduce_ch4<16>(acc);
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    if (lane < 4) {
+#pragma unroll
+        for (int i = 0; i < 16; ++i) red[wave][lane][i] = acc[i];
+    }
+    __syncthreads();
+    if (threadIdx.x < 64) {
+        const int c4 = threadIdx.x >> 4, k = threadIdx.x & 15;
+        const float s = red[0][c4][k] + red[1][c4][k] + red[2][c4][k] + red[3][c4][k];
+        atomicAdd(sums + (k >> 3) * 32 + c4 * 8 + (k & 7), s);
+    }
+}
+
+// coef[0..31] = scale, coef[32..63] = shift; save[0..31] = mean, save[32..63] = invstd
+__global__ void bn_finalize_fwd_kernel(const float* __restrict__ sums, float n, const float* __restrict__ gamma,
+                                       const float* __restrict__ beta, float* __restrict__ rmean,
+                                       float* __restrict__ rvar, float momentum, float eps, int training,
+                                       float* __restrict__ coef, float* __restrict__ save) {
+    const int c = threadIdx.x;
+    if (c >= 32) return;
+    float mean, var;
+    if (training) {
+        mean = sums[c] / n;
+        var = fmaxf(sums[32 + c] / n - mean * mean, 0.f);
+        rmean[c] = (1.f - momentum) * rmean[c] + momentum * mean;
+        rvar[c] = (1.f - momentum) * rvar[c] + momentum * var * (n / fmaxf(n - 1.f, 1.f));
+    } else {
+        mean = rmean[c];
+        var = rvar[c];
+    }
+    const float invstd = rsqrtf(var + eps);
+    const float s = gamma[c] * invstd;
+    coef[c] = s;
+    coef[32 + c] = beta[c] - mean * s;
+    save[c] = mean;
+    save[32 + c] = invstd;
+}
+
+// BN backward: dy = a*g + b*y + d with a = gamma*invstd, b = -a*invstd*dgamma/n,
+// d = -a*sum_g/n - b*mean;  dgamma = invstd*(sum_gy - mean*sum_g), dbeta = sum_g.
+__global__ void bn_finalize_bwd_kernel(const float* __restrict__ sums, const float* __restrict__ save,
+                                       const float* __restrict__ gamma, float n, float* __restrict__ coef3,
+                                       float* __restrict__ ggamma, float* __restrict__ gbeta) {
+    const int c = threadIdx.x;
+    if (c >= 32) return;
+    const float mean = save[c], invstd = save[32 + c];
+    const float sg = sums[c], sgy = sums[32 + c];
+    const float dgamma = invstd * (sgy - mean * sg);
+    const float a = gamma[c] * invstd;
+    const float bq = -a * invstd * dgamma / n;
+    coef3[c] = a;
+    coef3[32 + c] = bq;
+    coef3[64 + c] = -a * sg / n - bq * mean;
+    ggamma[c] += dgamma;
+    gbeta[c] += sg;
+}
+
+struct Strides { int64_t sb, sf, st; };
+
+// z = relu(s*y2 + t + x); z may live in another layout (granule address b*sb + f*sf + t*st)
+__global__ __launch_bounds__(256) void block_out_kernel(const __hip_bfloat16* __restrict__ y2,
+                                                        const float* __restrict__ coef,
+                                                        const __hip_bfloat16* __restrict__ x, int B, int F,
+                                                        int T, __hip_bfloat16* __restrict__ z, Strides zs) {
+    const int ch4 = threadIdx.x & 3;
+    float s[8], sh[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) { s[j] = coef[ch4 * 8 + j]; sh[j] = coef[32 + ch4 * 8 + j]; }
+    const int64_t n = (int64_t)B * F * T;
+    for (int64_t c = (int64_t)blockIdx.x * 256 + threadIdx.x; c < n * 4; c += (int64_t)gridDim.x * 256) {
+        const int64_t p = c >> 2;
+        float a[8], xv[8];
+        unpack8(*reinterpret_cast<const uint4*>(y2 + c * 8), a);
+        unpack8(*reinterpret_cast<const uint4*>(x + c * 8), xv);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) a[j] = fmaxf(0.f, s[j] * a[j] + sh[j] + xv[j]);
+        const int t = (int)(p % T);
+        const int64_t bf = p / T;
+        const int64_t off = (bf / F) * zs.sb + (bf % F) * zs.sf + (int64_t)t * zs.st + ch4 * 8;
+        *reinterpret_cast<uint4*>(z + off) = pack8(a);
+    }
+}
+
+// g2pre = gz * [z > 0] (gz, z in the strided layout), sums += (sum g2pre, sum g2pre*y2)
+__global__ __launch_bounds__(256) void block_bwd_in_kernel(const __hip_bfloat16* __restrict__ gz,
+                                                           const __hip_bfloat16* __restrict__ z, Strides zs,
+                                                           const __hip_bfloat16* __restrict__ y2, int B, int F,
+                                                           int T, __hip_bfloat16* __restrict__ gpre,
+                                                           float* __restrict__ sums) {
+    __shared__ float red[4][4][16];
+    const int ch4 = threadIdx.x & 3;
+    float acc[16];
+#pragma unroll
+    for (int i = 0; i < 16; ++i) acc[i] = 0.f;
+    const int64_t n = (int64_t)B * F * T;
+    for (int64_t c = (int64_t)blockIdx.x * 256 + threadIdx.x; c < n * 4; c += (int64_t)gridDim.x * 256) {
+        const int64_t p = c >> 2;
+        const int t = (int)(p % T);
+        const int64_t bf = p / T;
+        const int64_t off = (bf / F) * zs.sb + (bf % F) * zs.sf + (int64_t)t * zs.st + ch4 * 8;
+        float gv[8], zv[8], yv[8];
+        unpack8(*reinterpret_cast<const uint4*>(gz + off), gv);
+        unpack8(*reinterpret_cast<const uint4*>(z + off), zv);
+        unpack8(*reinterpret_cast<const uint4*>(y2 + c * 8), yv);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            gv[j] = zv[j] > 0.f ? gv[j] : 0.f;
+            acc[j] += gv[j];
+            acc[8 + j] += gv[j] * yv[j];
+        }
+        *reinterpret_cast<uint4*>(gpre + c * 8) = pack8(gv);
+    }
+    reduce_ch4<16>(acc);
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    if (lane < 4) {
+#pragma unroll
+        for (int i = 0; i < 16; ++i) red[wave][lane][i] = acc[i];
+    }
+    __syncthreads();
+    if (threadIdx.x < 64) {
+        const int c4 = threadIdx.x >> 4, k = threadIdx.x & 15;
+        const float sm = red[0][c4][k] + red[1][c4][k] + red[2][c4][k] + red[3][c4][k];
+        atomicAdd(sums + (k >> 3) * 32 + c4 * 8 + (k & 7), sm);
+    }
+}
+
+static int stream_blocks(int64_t chunks) {
+    int64_t b = (chunks + 255) / 256;
+    if (b > 2048) b = 2048;
+    if (b < 1) b = 1;
+    return (int)b;
+}
+
+static int check_act(const char* who, int B, int F, int T) {
+    SP_CHECK_ARG(B >= 1 && F >= 1 && T >= 1 && B <= 65535, "%s: bad shape B=%d F=%d T=%d", who, B, F, T);
+    return SP_OK;
+}
+
+}  // namespace sp
+
+using namespace sp;
+typedef __hip_bfloat16 bf16;
+
+extern "C" int sp_conv_pack_w(const float* w, int bwd_data, void* wpack, void* stream) {
+    SP_CHECK_ARG(w && wpack, "sp_conv_pack_w: null pointer");
+    hipLaunchKernelGGL(conv_pack_kernel, dim3(60), dim3(256), 0, (hipStream_t)stream, w, bwd_data, (bf16*)wpack);
+    return check_launch("conv_pack_kernel");
+}
+
+extern "C" int sp_conv3x5(const void* in, const void* in2, const float* coef, int in_mode, const void* wpack,
+                          const float* bias, const void* epi_src, const float* epi_coef, int epi_mode, int B,
+                          int F, int T, void* out, void* stream) {
+    int rc = check_act("sp_conv3x5", B, F, T);
+    if (rc) return rc;
+    SP_CHECK_ARG(in && wpack && out, "sp_conv3x5: null pointer");
+    SP_CHECK_ARG(in_mode == IN_ID || coef, "sp_conv3x5: input transform needs coefficients");
+    SP_CHECK_ARG(in_mode != IN_BNBWD || in2, "sp_conv3x5: BN-backward transform needs the second input");
+    SP_CHECK_ARG(epi_mode == EPI_NONE || epi_src, "sp_conv3x5: epilogue needs its source tensor");
+    SP_CHECK_ARG(epi_mode != EPI_MASK || epi_coef, "sp_conv3x5: mask epilogue needs coefficients");
+    dim3 grid((T + kTP - 1) / kTP, (F + kFR - 1) / kFR, B), blk(256);
+    hipStream_t s = (hipStream_t)stream;
+#define SP_CONV_LAUNCH(IM, EP)                                                                          \
+    hipLaunchKernelGGL((conv3x5_kernel<IM, EP>), grid, blk, 0, s, (const bf16*)in, (const bf16*)in2, coef, \
+                       (const bf16*)wpack, bias, (const bf16*)epi_src, epi_coef, B, F, T, (bf16*)out)
+    if (in_mode == IN_ID && epi_mode == EPI_NONE) SP_CONV_LAUNCH(IN_ID, EPI_NONE);
+    else if (in_mode == IN_BNRELU && epi_mode == EPI_NONE) SP_CONV_LAUNCH(IN_BNRELU, EPI_NONE);
+    else if (in_mode == IN_BNBWD && epi_mode == EPI_MASK) SP_CONV_LAUNCH(IN_BNBWD, EPI_MASK);
+    else if (in_mode == IN_BNBWD && epi_mode == EPI_ADD) SP_CONV_LAUNCH(IN_BNBWD, EPI_ADD);
+    else return fail(SP_EINVAL, "sp_conv3x5: unsupported mode pair (%d, %d)", in_mode, epi_mode);
+#undef SP_CONV_LAUNCH
+    return check_launch("conv3x5_kernel");
+}
+
+extern "C" int sp_conv3x5_wgrad(const void* a_src, const float* a_coef, int a_mode, const void* g,
+                                const void* y, const float* g_coef, int B, int F, int T, float* gwp_ws,
+                                float* gw, void* stream) {
+    int rc = check_act("sp_conv3x5_wgrad", B, F, T);
+    if (rc) return rc;
+    SP_CHECK_ARG(a_src && g && y && g_coef && gwp_ws && gw, "sp_conv3x5_wgrad: null pointer");
+    SP_CHECK_ARG(a_mode == IN_ID || (a_mode == IN_BNRELU && a_coef), "sp_conv3x5_wgrad: bad activation mode");
+    hipStream_t s = (hipStream_t)stream;
+    hipError_t e = hipMemsetAsync(gwp_ws, 0, 15 * 32 * 32 * sizeof(float), s);
+    if (e != hipSuccess) return fail(SP_ELAUNCH, "sp_conv3x5_wgrad: %s", hipGetErrorString(e));
+    const int fsplit = F >= 8 ? 2 : 1;
+    dim3 grid((T + 63) / 64, B * fsplit), blk(320);
+    if (a_mode == IN_ID)
+        hipLaunchKernelGGL((conv3x5_wgrad_kernel<IN_ID>), grid, blk, 0, s, (const bf16*)a_src, a_coef,
+                           (const bf16*)g, (const bf16*)y, g_coef, B, F, T, fsplit, gwp_ws);
+    else
+        hipLaunchKernelGGL((conv3x5_wgrad_kernel<IN_BNRELU>), grid, blk, 0, s, (const bf16*)a_src, a_coef,
+                           (const bf16*)g, (const bf16*)y, g_coef, B, F, T, fsplit, gwp_ws);
+    rc = check_launch("conv3x5_wgrad_kernel");
+    if (rc) return rc;
+    hipLaunchKernelGGL(conv_wgrad_unpack_kernel, dim3(60), dim3(256), 0, s, gwp_ws, gw);
+    return check_launch("conv_wgrad_unpack_kernel");
+}
+
+extern "C" int sp_conv_stem_fwd(const float* spec, const float* w, const float* bias, int B, int Fin, int Tin,
+                                void* out, void* stream) {
+    SP_CHECK_ARG(B >= 1 && Fin >= 1 && Tin >= 1, "sp_conv_stem_fwd: bad shape");
+    SP_CHECK_ARG(spec && w && bias && out, "sp_conv_stem_fwd: null pointer");
+    const int F = (Fin - 1) / 2 + 1, T = (Tin - 1) / 2 + 1;
+    hipLaunchKernelGGL(stem_fwd_kernel, dim3(stream_blocks((int64_t)B * F * T)), dim3(256), 0,
+                       (hipStream_t)stream, spec, w, bias, B, Fin, Tin, F, T, (bf16*)out);
+    return check_launch("stem_fwd_kernel");
+}
+
+extern "C" int sp_conv_stem_bwd(const float* spec, const void* gout, int B, int Fin, int Tin, float* gw,
+                                float* gbias, void* stream) {
+    SP_CHECK_ARG(B >= 1 && Fin >= 1 && Tin >= 1, "sp_conv_stem_bwd: bad shape");
+    SP_CHECK_ARG(spec && gout && gw && gbias, "sp_conv_stem_bwd: null pointer");
+    const int F = (Fin - 1) / 2 + 1, T = (Tin - 1) / 2 + 1;
+    int blocks = stream_blocks((int64_t)B * F * T * 4);
+    if (blocks > 512) blocks = 512;
+    hipLaunchKernelGGL(stem_bwd_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, spec,
+                       (const bf16*)gout, B, Fin, Tin, F, T, gw, gbias);
+    return check_launch("stem_bwd_kernel");
+}
+
+extern "C" int sp_bn_stats(const void* y, int64_t npos, float* sums, void* stream) {
+    SP_CHECK_ARG(y && sums && npos >= 1, "sp_bn_stats: bad arguments");
+    hipStream_t s = (hipStream_t)stream;
+    hipError_t e = hipMemsetAsync(sums, 0, 64 * sizeof(float), s);
+    if (e != hipSuccess) return fail(SP_ELAUNCH, "sp_bn_stats: %s", hipGetErrorString(e));
+    hipLaunchKernelGGL((bn_reduce_kernel<0>), dim3(stream_blocks(npos * 4)), dim3(256), 0, s, (const bf16*)y,
+                       (const bf16*)nullptr, npos, sums);
+    return check_launch("bn_reduce_kernel<0>");
+}
+
+extern "C" int sp_bn_bwd_reduce(const void* g, const void* y, int64_t npos, float* sums, void* stream) {
+    SP_CHECK_ARG(g && y && sums && npos >= 1, "sp_bn_bwd_reduce: bad arguments");
+    hipStream_t s = (hipStream_t)stream;
+    hipError_t e = hipMemsetAsync(sums, 0, 64 * sizeof(float), s);
+    if (e != hipSuccess) return fail(SP_ELAUNCH, "sp_bn_bwd_reduce: %s", hipGetErrorString(e));
+    hipLaunchKernelGGL((bn_reduce_kernel<1>), dim3(stream_blocks(npos * 4)), dim3(256), 0, s, (const bf16*)g,
+                       (const bf16*)y, npos, sums);
+    return check_launch("bn_reduce_kernel<1>");
+}
+
+extern "C" int sp_bn_finalize_fwd(const float* sums, int64_t npos, const float* gamma, const float* beta,
+                                  float* rmean, float* rvar, float momentum, float eps, int training,
+                                  float* coef, float* save, void* stream) {
+    SP_CHECK_ARG(gamma && beta && rmean && rvar && coef && save && (sums || !training),
+                 "sp_bn_finalize_fwd: null pointer");
+    hipLaunchKernelGGL(bn_finalize_fwd_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, sums, (float)npos,
+                       gamma, beta, rmean, rvar, momentum, eps, training, coef, save);
+    return check_launch("bn_finalize_fwd_kernel");
+}
+
+extern "C" int sp_bn_finalize_bwd(const float* sums, const float* save, const float* gamma, int64_t npos,
+                                  float* coef3, float* ggamma, float* gbeta, void* stream) {
+    SP_CHECK_ARG(sums && save && gamma && coef3 && ggamma && gbeta, "sp_bn_finalize_bwd: null pointer");
+    hipLaunchKernelGGL(bn_finalize_bwd_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, sums, save, gamma,
+                       (float)npos, coef3, ggamma, gbeta);
+    return check_launch("bn_finalize_bwd_kernel");
+}
+
+extern "C" int sp_block_out(const void* y2, const float* coef, const void* x, int B, int F, int T, void* z,
+                            int64_t zsb, int64_t zsf, int64_t zst, void* stream) {
+    int rc = check_act("sp_block_out", B, F, T);
+    if (rc) return rc;
+    SP_CHECK_ARG(y2 && coef && x && z, "sp_block_out: null pointer");
+    SP_CHECK_ARG(zsb % 8 == 0 && zsf % 8 == 0 && zst % 8 == 0, "sp_block_out: strides must keep 16-byte chunks aligned");
+    Strides zs{zsb, zsf, zst};
+    hipLaunchKernelGGL(block_out_kernel, dim3(stream_blocks((int64_t)B * F * T * 4)), dim3(256), 0,
+                       (hipStream_t)stream, (const bf16*)y2, coef, (const bf16*)x, B, F, T, (bf16*)z, zs);
+    return check_launch("block_out_kernel");
+}
+
+extern "C" int sp_block_bwd_in(const void* gz, const void* z, int64_t zsb, int64_t zsf, int64_t zst,
+                               const void* y2, int B, int F, int T, void* gpre, float* sums, void* stream) {
+    int rc = check_act("sp_block_bwd_in", B, F, T);
+    if (rc) return rc;
+    SP_CHECK_ARG(gz && z && y2 && gpre && sums, "sp_block_bwd_in: null pointer");
+    SP_CHECK_ARG(zsb % 8 == 0 && zsf % 8 == 0 && zst % 8 == 0, "sp_block_bwd_in: strides must keep 16-byte chunks aligned");
+    hipStream_t s = (hipStream_t)stream;
+    hipError_t e = hipMemsetAsync(sums, 0, 64 * sizeof(float), s);
+    if (e != hipSuccess) return fail(SP_ELAUNCH, "sp_block_bwd_in: %s", hipGetErrorString(e));
+    Strides zs{zsb, zsf, zst};
+    hipLaunchKernelGGL(block_bwd_in_kernel, dim3(stream_blocks((int64_t)B * F * T * 4)), dim3(256), 0, s,
+                       (const bf16*)gz, (const bf16*)z, zs, (const bf16*)y2, B, F, T, (bf16*)gpre, sums);
+    return check_launch("block_bwd_in_kernel");
+}

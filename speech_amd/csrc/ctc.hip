@@ -18,14 +18,15 @@
 //   K3 ctc_grad    (whole chip, one wave per (t,b) row): posterior per state
 //                  2^(alpha+beta-lp+nll), summed per class in LDS, grad = (softmax - occ)*scale.
 //
-// Workspace: lse2[B*T] | rows[B][T][RW] | alpha[B][T][SP] | beta_rev[B][T][SP] (f32), then
-// f64 aoff[B*T] | boff[B*T] | nll2[B].
+// Workspace: lse2[B*T] | rows[B][T][RW] (f32), then f64 alpha[B][T][SP] | beta_rev[B][T][SP] | nll2[B].
 //
 // Precision: alpha/beta reach thousands of log2 units, where one f32 ulp is ~2e-4 and a plain
 // f32 log-space recursion (torch's included) random-walks to ~3e-4 relative error in the
 // posteriors.  K2 keeps the lattice states in f64 registers (the adds; exp2/log2 of the small
-// terms stay f32) and spills each row as f32 relative to an f64 per-row offset (the row maximum,
-// refreshed every 4 frames); K3 adds the f64 scalars (aoff + boff - log-likelihood) once per row.
+// terms stay f32) and spills the rows as f64: for tightly constrained alignments the states that
+// carry the posterior sit hundreds of units below the row maximum, so an f32 spill relative to
+// any per-row offset loses the same digits again.  K3 forms alpha + beta - lp - log-likelihood
+// in f64 and exponentiates in f32.
 #include "common.h"
 
 namespace sp {
@@ -40,8 +41,8 @@ struct CtcDims {
     int RW;    // row width in floats (multiple of 4)
     int SP;    // padded lattice row (multiple of 8)
     int modeB; // 1: rows indexed by class, 0: by label position
-    size_t off_lse, off_rows, off_alpha, off_beta, total_floats;  // float offsets
-    size_t off_dbl;  // float offset of the double block: aoff[B*T] | boff[B*T] | nll2[B]
+    size_t off_lse, off_rows, total_floats;  // float offsets
+    size_t off_dbl;  // float offset of the f64 block: alpha[B][T][SP] | beta_rev[B][T][SP] | nll2[B]
     size_t total_bytes;
 };
 
@@ -54,11 +55,9 @@ static CtcDims ctc_dims(int T, int B, int V, int Lmax) {
     size_t o = 0;
     d.off_lse = o; o += align_up((size_t)B * T, 4);
     d.off_rows = o; o += (size_t)B * T * d.RW;
-    d.off_alpha = o; o += (size_t)B * T * d.SP;
-    d.off_beta = o; o += (size_t)B * T * d.SP;
     o = align_up(o, 4);
     d.off_dbl = o;
-    o += 2 * ((size_t)2 * B * T + B);  // doubles, counted in floats
+    o += 2 * ((size_t)2 * B * T * d.SP + B);  // doubles, counted in floats
     d.total_floats = o;
     d.total_bytes = o * sizeof(float);
     return d;
@@ -138,15 +137,13 @@ template <int W, int NS>
 __global__ __launch_bounds__(64 * W) void ctc_lattice_kernel(
     const float* __restrict__ rows, const int64_t* __restrict__ labels, int label_stride,
     const int32_t* __restrict__ in_len, const int32_t* __restrict__ lab_len, int T, int V,
-    int blank, int Lmax, int RW, int SP, int modeB, int TB, float* __restrict__ alpha,
-    float* __restrict__ beta_rev, double* __restrict__ aoff, double* __restrict__ boff,
-    double* __restrict__ nll2, float* __restrict__ nll) {
+    int blank, int Lmax, int RW, int SP, int modeB, int TB, double* __restrict__ alpha,
+    double* __restrict__ beta_rev, double* __restrict__ nll2, float* __restrict__ nll) {
     constexpr int NT = 64 * W;
     // LDS: two row-chunk buffers of kPF*NT float4 each, then boundary slots, then final pair
     __shared__ __attribute__((aligned(16))) float4 s_chunk[2][kPF * NT];
     __shared__ double s_bnd[2][W][2];  // per wave: last state, second-to-last
     __shared__ double s_fin[2];
-    __shared__ float s_max[W];
 
     const int b = blockIdx.x, dir = blockIdx.y;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -154,8 +151,7 @@ __global__ __launch_bounds__(64 * W) void ctc_lattice_kernel(
     const int L = min(max(lab_len[b], 0), Lmax);
     const int S = 2 * L + 1;
     const int64_t* lab = labels + (int64_t)b * label_stride;
-    float* out = (dir ? beta_rev : alpha) + (int64_t)b * T * SP;
-    double* ooff = (dir ? boff : aoff) + (int64_t)b * T;
+    double* out = (dir ? beta_rev : alpha) + (int64_t)b * T * SP;
     const float* rows_b = rows + (int64_t)b * T * RW;
 
     if (Tb == 0) {
@@ -218,7 +214,6 @@ __global__ __launch_bounds__(64 * W) void ctc_lattice_kernel(
 #pragma unroll
     for (int j = 0; j < NS; ++j) a[j] = kNegInf;
 
-    double offs = 0.0;  // f64 offset the stored f32 rows are relative to: true alpha = stored + offs
     int i = 0;
     for (int c = 0; c < nchunks; ++c) {
         if (c + 1 < nchunks) SP_CTC_ISSUE(c + 1);
@@ -257,37 +252,11 @@ __global__ __launch_bounds__(64 * W) void ctc_lattice_kernel(
 #pragma unroll
                 for (int j = 0; j < NS; ++j) a[j] = n_[j];
             }
-            // every 4th frame: refresh the storage offset with this row's maximum (uniform branch)
-            if ((i & 3) == 0) {
-                double mx = kNegInf;
+            // spill the lattice row (coalesced 16-byte stores)
+            double* orow = out + (int64_t)t * SP + tid * NS;
 #pragma unroll
-                for (int j = 0; j < NS; ++j) mx = fmax(mx, a[j]);
-                float mxf = wave_max((float)mx);  // an f32 max is plenty for an offset
-                if (W > 1) {
-                    if (lane == 0) s_max[wave] = mxf;
-                    __syncthreads();
-#pragma unroll
-                    for (int w = 0; w < W; ++w) mxf = fmaxf(mxf, s_max[w]);
-                }
-                if (mxf != -INFINITY) offs = (double)mxf;
-            }
-            // spill the lattice row relative to offs (coalesced, vector stores)
-            float st_[NS];
-#pragma unroll
-            for (int j = 0; j < NS; ++j) st_[j] = (float)(a[j] - offs);
-            float* orow = out + (int64_t)t * SP + tid * NS;
-            if (tid * NS < SP) {
-                if constexpr (NS == 2) {
-                    *reinterpret_cast<float2*>(orow) = make_float2(st_[0], st_[1]);
-                } else if constexpr (NS == 4) {
-                    *reinterpret_cast<float4*>(orow) = make_float4(st_[0], st_[1], st_[2], st_[3]);
-                } else {
-                    *reinterpret_cast<float4*>(orow) = make_float4(st_[0], st_[1], st_[2], st_[3]);
-                    if (tid * NS + 4 < SP)
-                        *reinterpret_cast<float4*>(orow + 4) = make_float4(st_[4], st_[5], st_[6], st_[7]);
-                }
-            }
-            if (tid == 0) ooff[t] = offs;
+            for (int j = 0; j < NS; j += 2)
+                if (tid * NS + j < SP) *reinterpret_cast<double2*>(orow + j) = make_double2(a[j], a[j + 1]);
             if (W > 1) {
                 if (lane == 63) {
                     s_bnd[(i + 1) & 1][wave][0] = a[NS - 1];
@@ -323,9 +292,8 @@ __global__ __launch_bounds__(256) void ctc_grad_kernel(
     const float* __restrict__ logits, int64_t st, int64_t sb, const int64_t* __restrict__ labels,
     int label_stride, const int32_t* __restrict__ in_len, const int32_t* __restrict__ lab_len,
     int T, int B, int V, int blank, int Lmax, int RW, int SP, int modeB,
-    const float* __restrict__ lse2, const float* __restrict__ rows, const float* __restrict__ alpha,
-    const float* __restrict__ beta_rev, const double* __restrict__ aoff,
-    const double* __restrict__ boff, const double* __restrict__ nll2d,
+    const float* __restrict__ lse2, const float* __restrict__ rows, const double* __restrict__ alpha,
+    const double* __restrict__ beta_rev, const double* __restrict__ nll2d,
     const float* __restrict__ nll, float grad_scale, float* __restrict__ grad,
     float* __restrict__ loss) {
     extern __shared__ __attribute__((aligned(16))) float s_occ[];  // [waves][V]
@@ -352,10 +320,10 @@ __global__ __launch_bounds__(256) void ctc_grad_kernel(
         }
         const int L = min(max(lab_len[b], 0), Lmax);
         const int S = 2 * L + 1;
-        const float nll2 = (float)(aoff[(int64_t)b * T + t] + boff[(int64_t)b * T + t] + nll2d[b]);
+        const double nll2 = nll2d[b];
         const float scale = grad_scale / ((float)B * (float)max(L, 1));
-        const float* arow = alpha + ((int64_t)b * T + t) * SP;
-        const float* brow = beta_rev + ((int64_t)b * T + t) * SP;
+        const double* arow = alpha + ((int64_t)b * T + t) * SP;
+        const double* brow = beta_rev + ((int64_t)b * T + t) * SP;
         const float* lrow = rows + ((int64_t)b * T + t) * RW;
         const int64_t* lab = labels + (int64_t)b * label_stride;
 
@@ -365,7 +333,7 @@ __global__ __launch_bounds__(256) void ctc_grad_kernel(
             int cls = blank;
             if (s & 1) cls = min(max((int)lab[(s - 1) >> 1], 0), V - 1);
             const int ri = modeB ? cls : ((s & 1) ? (s + 1) >> 1 : 0);
-            const float gam = exp2f((arow[s] + brow[S - 1 - s] - lrow[ri]) + nll2);
+            const float gam = exp2f((float)(arow[s] + brow[S - 1 - s] - (double)lrow[ri] + nll2));
             if (s & 1) atomicAdd(&occ[cls], gam);
             else blank_acc += gam;
         }
@@ -392,8 +360,8 @@ static void launch_lattice(const CtcDims& d, float* ws, const int64_t* labels, i
     if (TB < 1) TB = 1;
     hipLaunchKernelGGL((ctc_lattice_kernel<W, NS>), dim3(d.B, 2), dim3(64 * W), 0, s,
                        ws + d.off_rows, labels, label_stride, in_len, lab_len, d.T, d.V, blank,
-                       d.Lmax, d.RW, d.SP, d.modeB, TB, ws + d.off_alpha, ws + d.off_beta,
-                       dbl, dbl + (size_t)d.B * d.T, dbl + (size_t)2 * d.B * d.T, nll);
+                       d.Lmax, d.RW, d.SP, d.modeB, TB, dbl, dbl + (size_t)d.B * d.T * d.SP,
+                       dbl + (size_t)2 * d.B * d.T * d.SP, nll);
 }
 
 }  // namespace sp
@@ -453,8 +421,8 @@ extern "C" int sp_ctc_fwd_bwd(const float* logits, int64_t stride_t, int64_t str
         hipLaunchKernelGGL(ctc_grad_kernel, dim3(gb), dim3(256), lds, s, logits, stride_t, stride_b,
                            labels, label_stride, input_lengths, label_lengths, T, B, V, blank,
                            max_label_len, d.RW, d.SP, d.modeB, ws + d.off_lse, ws + d.off_rows,
-                           ws + d.off_alpha, ws + d.off_beta, dbl, dbl + (size_t)B * T,
-                           dbl + (size_t)2 * B * T, nll, grad_scale, T > 0 ? grad : nullptr, loss);
+                           dbl, dbl + (size_t)B * T * d.SP, dbl + (size_t)2 * B * T * d.SP, nll,
+                           grad_scale, T > 0 ? grad : nullptr, loss);
         rc = check_launch("ctc_grad_kernel");
         if (rc) return rc;
     }

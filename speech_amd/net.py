@@ -6,9 +6,11 @@ state_dict keys: cnn.{weight,bias}; resnet_layers.{0,1,2}.
 .{bn1,bn2}.*; sru_layers.rnn_lst.{i}.{weight,weight_c,bias,layer_norm.weight,layer_norm.bias}
 (+ scale_x buffer); classifier.0.{weight,bias}; classifier.1.weight.
 
-The SRU recurrence runs in the HIP kernels (ops.sru_recurrence).  ``compute_dtype`` selects the
-activation type of the encoder: float32 (parity) or bfloat16 (throughput; the reference trains
-under fp16 autocast with an fp16 recurrence, net.py:71).
+The conv/BatchNorm stack (speech_amd.convstack) and the SRU recurrence (ops.sru_recurrence) run
+in the HIP kernels.  The conv stack always keeps bf16 activations; ``compute_dtype`` selects the
+activation type of the SRU stack and classifier: float32 or bfloat16 (the reference trains under
+fp16 autocast with an fp16 recurrence, net.py:71).  ResidualBlock.forward below is the plain
+torch statement of one block and is used only by tests as the reference of the kernels.
 """
 import math
 
@@ -16,7 +18,7 @@ import torch
 import torch.nn as nn
 import torch.nn.functional as F
 
-from . import ops
+from . import convstack, ops
 
 
 class ResidualBlock(nn.Module):
@@ -52,9 +54,12 @@ class SRUCell(nn.Module):
     permuted view of it.
     """
 
-    def __init__(self, input_size, hidden_size, dropout=0.0, highway_bias=0.0):
+    def __init__(self, input_size, hidden_size, dropout=0.0, highway_bias=0.0, in_layout=None):
         super().__init__()
         self.input_size, self.hidden_size = input_size, hidden_size
+        # in_layout = (C, F): the input arrives with feature index f*C + c while `weight` rows and
+        # the layer-norm vectors are stored in the reference's c*F + f order (net.py:82)
+        self.in_layout = in_layout
         self.output_size = 2 * hidden_size
         self.dropout = dropout
         self.num_matrices = 3 if input_size == self.output_size else 4
@@ -85,13 +90,22 @@ class SRUCell(nn.Module):
         """[n_in, k, 2, d] column order for the kernels, flattened, in the compute dtype."""
         k, d = self.num_matrices, self.hidden_size
         w = self.weight.view(self.input_size, 2, d, k).permute(0, 3, 1, 2)
+        if self.in_layout is not None:
+            C, Fq = self.in_layout
+            w = w.reshape(C, Fq, k, 2, d).transpose(0, 1)
         return w.reshape(self.input_size, k * 2 * d).to(dtype)
+
+    def _ln_vec(self, v, dtype):
+        if self.in_layout is not None:
+            C, Fq = self.in_layout
+            v = v.view(C, Fq).t().reshape(-1)
+        return v.to(dtype)
 
     def forward(self, x):
         T, B, n_in = x.shape
         k, d = self.num_matrices, self.hidden_size
         ln = self.layer_norm
-        xn = F.layer_norm(x, (n_in,), ln.weight.to(x.dtype), ln.bias.to(x.dtype), ln.eps)
+        xn = F.layer_norm(x, (n_in,), self._ln_vec(ln.weight, x.dtype), self._ln_vec(ln.bias, x.dtype), ln.eps)
         U = (xn.reshape(T * B, n_in) @ self.kernel_weight(x.dtype)).view(T, B, k, 2, d)
         mask = None
         if self.training and self.dropout > 0:
@@ -105,14 +119,15 @@ class SRU(nn.Module):
     rescale=False, highway_bias=0): dropout on every layer but the last."""
 
     def __init__(self, input_size, hidden_size, num_layers, dropout=0.0, projection_size=0,
-                 highway_bias=0.0):
+                 highway_bias=0.0, in_layout=None):
         super().__init__()
         if projection_size:
             raise NotImplementedError("projection_size > 0 (weight_proj) is not built; the reference "
                                       "trains with projection_size=0 (train.py:319)")
         self.rnn_lst = nn.ModuleList(
             SRUCell(input_size if i == 0 else 2 * hidden_size, hidden_size,
-                    dropout=dropout if i + 1 != num_layers else 0.0, highway_bias=highway_bias)
+                    dropout=dropout if i + 1 != num_layers else 0.0, highway_bias=highway_bias,
+                    in_layout=in_layout if i == 0 else None)
             for i in range(num_layers))
 
     def forward(self, x):
@@ -129,22 +144,16 @@ class SRModel(nn.Module):
         self.resnet_layers = nn.Sequential(*[ResidualBlock(32, 32, t_kernel_s=5) for _ in range(3)])
         n_features = 32 * n_feats // 2
         self.sru_layers = SRU(n_features, rnn_dim, n_rnn_layers, dropout=dropout,
-                              projection_size=projection_size)
+                              projection_size=projection_size, in_layout=(32, n_feats // 2))
         self.classifier = nn.Sequential(nn.LayerNorm(2 * rnn_dim),
                                         nn.Linear(2 * rnn_dim, n_vocab + 1, bias=False))
         self.compute_dtype = compute_dtype
 
-    def forward(self, x):  # [B, 1, F, T]
+    def forward(self, x):  # [B, 1, F, T] f32 spectrogram
         cd = self.compute_dtype
-        if cd == torch.float32:
-            x = self.resnet_layers(self.cnn(x.float()))
-        else:
-            with torch.autocast("cuda", dtype=cd):
-                x = self.resnet_layers(self.cnn(x))
-            x = x.to(cd)
-        B, C, Fq, T = x.shape
-        x = x.reshape(B, C * Fq, T).permute(2, 0, 1).contiguous()  # [T', B, 1280], feature = c*40+f
-        x, _ = self.sru_layers(x)
+        # conv stack on the channel-last bf16 kernels -> [T', B, (F/2)*32], feature = f*32 + c
+        x = convstack.conv_stack(x, self.cnn, list(self.resnet_layers), self.training)
+        x, _ = self.sru_layers(x.to(cd))
         x = x.transpose(0, 1).contiguous()  # [B, T', 2*rnn_dim]
         ln, lin = self.classifier[0], self.classifier[1]
         x = F.layer_norm(x, (x.shape[-1],), ln.weight.to(cd), ln.bias.to(cd), ln.eps)

@@ -349,3 +349,164 @@ def test_sru_matches_layer_oracle(cuda):
     U = (xn.reshape(T * B, n_in) @ W).view(T, B, 2, d, 3).permute(0, 1, 4, 2, 3).contiguous()  # -> [T,B,k,2,d]
     h = ops.sru_recurrence(U.to(cuda), x.to(cuda), wc.to(cuda), bias.to(cuda), None, d)
     assert float((h.cpu() - href).abs().max()) <= 2e-5 * max(1.0, float(href.abs().max()))
+
+
+# =============================================================================== conv stack
+def _conv_ref_and_hip(cuda, B, Fin, Tin, seed, train=True):
+    """torch fp32 statement of net.py:56-59 + :6-42 (the reference's own ops) vs the HIP stack."""
+    from speech_amd import convstack, net
+    torch.manual_seed(seed)
+    cnn = torch.nn.Conv2d(1, 32, 3, stride=2, padding=1).to(cuda)
+    blocks = [net.ResidualBlock(32, 32, 5).to(cuda) for _ in range(2)]
+    for blk in blocks:
+        for bn in (blk.bn1, blk.bn2):
+            bn.weight.data.uniform_(0.5, 1.5)
+            bn.bias.data.uniform_(-0.3, 0.3)
+    spec = torch.rand(B, 1, Fin, Tin, device=cuda) * 2
+    import copy
+    cnn_r, blocks_r = copy.deepcopy(cnn), copy.deepcopy(blocks)
+    for m in [cnn_r] + blocks_r + [cnn] + blocks:
+        m.train(train)
+    y = cnn_r(spec)
+    for blk in blocks_r:
+        y = blk(y)
+    ref = y.permute(3, 0, 2, 1).reshape(y.shape[3], B, -1)            # [T', B, f*32 + c]
+    out = convstack.conv_stack(spec, cnn, blocks, train)
+    return spec, (cnn, blocks, out), (cnn_r, blocks_r, ref)
+
+
+@pytest.mark.parametrize("shape", [(2, 80, 301), (3, 16, 70), (1, 9, 131)])
+def test_conv_stack_forward(cuda, shape):
+    B, Fin, Tin = shape
+    _, (_, blocks, out), (_, blocks_r, ref) = _conv_ref_and_hip(cuda, B, Fin, Tin, 3)
+    assert out.shape == ref.shape and out.dtype == torch.bfloat16
+    err = float((out.float() - ref).abs().max())
+    assert err <= 3e-2 * float(ref.abs().max()), err            # bf16 activations through 5 convs
+    # running statistics follow torch's update rule
+    for a, b in zip(blocks, blocks_r):
+        assert torch.allclose(a.bn2.running_var, b.bn2.running_var, rtol=3e-2, atol=1e-3)
+        assert torch.allclose(a.bn1.running_mean, b.bn1.running_mean, rtol=3e-2, atol=2e-3)
+
+
+def test_conv_stack_eval_mode(cuda):
+    _, (_, _, out), (_, _, ref) = _conv_ref_and_hip(cuda, 2, 40, 90, 5, train=False)
+    assert float((out.float() - ref).abs().max()) <= 3e-2 * float(ref.abs().max())
+
+
+def _bf(x):
+    return x.to(torch.bfloat16)
+
+
+def _nhwc(x):   # [B,C,F,T] f32 -> [B,F,T,C] bf16
+    return _bf(x.permute(0, 2, 3, 1).contiguous())
+
+
+def _nchw(x):   # [B,F,T,C] bf16 -> [B,C,F,T] f32
+    return x.float().permute(0, 3, 1, 2).contiguous()
+
+
+def _relmax(a, b):
+    return float((a.float() - b.float()).abs().max()) / max(float(b.float().abs().max()), 1e-9)
+
+
+@pytest.mark.parametrize("shape", [(2, 7, 100), (1, 40, 751), (3, 4, 64)])
+def test_conv_kernels_individually(cuda, shape):
+    """Every backward-path kernel against torch on IDENTICAL bf16-representable operands, so the
+    comparison is not blurred by ReLU-mask flips: tolerance = bf16 output rounding (1e-2 of the
+    peak) for bf16 outputs, 2e-3 for f32 accumulations."""
+    from speech_amd import convstack as cs
+    from speech_amd._lib import check, lib, ptr, stream_ptr
+    B, Fq, T = shape
+    g_ = torch.Generator(device="cuda").manual_seed(B * 1000 + T)
+    rnd = lambda *sz: torch.randn(*sz, generator=g_, device=cuda)   # noqa: E731
+    w = rnd(32, 32, 3, 5) * 0.1
+    wq = _bf(w).float()
+    gten, yten, aten = _bf(rnd(B, Fq, T, 32)), _bf(rnd(B, Fq, T, 32)), _bf(rnd(B, Fq, T, 32))
+    coef3 = torch.cat([rnd(32) * 0.5 + 1, rnd(32) * 0.2, rnd(32) * 0.1]).contiguous()
+    coef2 = torch.cat([rnd(32) * 0.5 + 1, rnd(32) * 0.3]).contiguous()
+    gy = _bf(coef3[:32] * gten.float() + coef3[32:64] * yten.float() + coef3[64:]).float()   # staged value
+    gy_nchw = gy.permute(0, 3, 1, 2).contiguous()
+    # --- backward-data, mask epilogue
+    ref_gin = torch.nn.grad.conv2d_input((B, 32, Fq, T), wq, gy_nchw, padding=(1, 2))
+    keep = (coef2[:32] * aten.float() + coef2[32:]) > 0
+    out = cs._conv(gten, yten, coef3, cs.IN_BNBWD, cs._pack(w, 1), None, aten, coef2, cs.EPI_MASK, B, Fq, T)
+    ref = ref_gin.permute(0, 2, 3, 1) * keep
+    assert _relmax(out, ref) <= 1e-2
+    # --- backward-data, residual-add epilogue
+    out = cs._conv(gten, yten, coef3, cs.IN_BNBWD, cs._pack(w, 1), None, aten, None, cs.EPI_ADD, B, Fq, T)
+    assert _relmax(out, ref_gin.permute(0, 2, 3, 1) + aten.float()) <= 1e-2
+    # --- weight gradient, activation = relu(BN(a_src)) and identity
+    ws = torch.empty(15 * 32 * 32, device=cuda)
+    for mode in (cs.IN_BNRELU, cs.IN_ID):
+        act = _bf(torch.relu(coef2[:32] * aten.float() + coef2[32:])).float() if mode == cs.IN_BNRELU else aten.float()
+        ref_gw = torch.nn.grad.conv2d_weight(act.permute(0, 3, 1, 2).contiguous(), (32, 32, 3, 5), gy_nchw, padding=(1, 2))
+        gw = torch.zeros(32, 32, 3, 5, device=cuda)
+        check(lib().sp_conv3x5_wgrad(ptr(aten), ptr(coef2), mode, ptr(gten), ptr(yten), ptr(coef3), B, Fq, T,
+                                     ptr(ws), ptr(gw), stream_ptr()), "wgrad")
+        assert _relmax(gw, ref_gw) <= 2e-3, mode
+    # --- BN backward reduce / block backward entry
+    sums = torch.empty(64, device=cuda)
+    check(lib().sp_bn_bwd_reduce(ptr(gten), ptr(yten), B * Fq * T, ptr(sums), stream_ptr()), "reduce")
+    ref_s = torch.cat([gten.float().sum((0, 1, 2)), (gten.float() * yten.float()).sum((0, 1, 2))])
+    assert float((sums - ref_s).abs().max()) <= 2e-3 * float(ref_s.abs().max()) + 1e-2
+    zten = _bf(rnd(B, Fq, T, 32))
+    gpre = torch.empty_like(gten)
+    check(lib().sp_block_bwd_in(ptr(gten), ptr(zten), Fq * T * 32, T * 32, 32, ptr(yten), B, Fq, T, ptr(gpre),
+                                ptr(sums), stream_ptr()), "bwd_in")
+    ref_g = gten.float() * (zten.float() > 0)
+    assert torch.equal(gpre.float(), ref_g)
+    ref_s = torch.cat([ref_g.sum((0, 1, 2)), (ref_g * yten.float()).sum((0, 1, 2))])
+    assert float((sums - ref_s).abs().max()) <= 2e-3 * float(ref_s.abs().max()) + 1e-2
+    # --- BN finalize backward: coefficients reproduce torch's batch_norm backward
+    n = B * Fq * T
+    yv = yten.float().reshape(-1, 32).clone().requires_grad_(True)
+    gamma = rnd(32) * 0.3 + 1
+    mean, var = yv.mean(0), yv.var(0, unbiased=False)
+    invstd = (var + 1e-5).rsqrt()
+    (gamma * (yv - mean) * invstd).backward(gten.float().reshape(-1, 32))
+    save = torch.cat([mean.detach(), invstd.detach()]).contiguous()
+    c3 = torch.empty(96, device=cuda)
+    gg, gb = torch.zeros(32, device=cuda), torch.zeros(32, device=cuda)
+    check(lib().sp_bn_bwd_reduce(ptr(gten), ptr(yten), n, ptr(sums), stream_ptr()), "reduce")
+    check(lib().sp_bn_finalize_bwd(ptr(sums), ptr(save), ptr(gamma), n, ptr(c3), ptr(gg), ptr(gb), stream_ptr()), "fin")
+    dy = c3[:32] * gten.float().reshape(-1, 32) + c3[32:64] * yten.float().reshape(-1, 32) + c3[64:]
+    assert _relmax(dy, yv.grad) <= 2e-3
+    # --- stem backward
+    Fin, Tin = 2 * Fq - 1, 2 * T
+    spec = rnd(B, 1, Fin, Tin)
+    assert (Fin - 1) // 2 + 1 == Fq and (Tin - 1) // 2 + 1 == T
+    gsw, gsb = torch.zeros(288, device=cuda), torch.zeros(32, device=cuda)
+    check(lib().sp_conv_stem_bwd(ptr(spec), ptr(gten), B, Fin, Tin, ptr(gsw), ptr(gsb), stream_ptr()), "stem")
+    gn = gten.float().permute(0, 3, 1, 2).contiguous()
+    ref_w = torch.nn.grad.conv2d_weight(spec, (32, 1, 3, 3), gn, stride=2, padding=1)
+    assert _relmax(gsw.view(32, 1, 3, 3), ref_w) <= 2e-3
+    assert _relmax(gsb, gn.sum((0, 2, 3))) <= 2e-3
+
+
+def test_conv_stack_backward(cuda):
+    """End to end against torch fp32 with loss = sum(z^2)/2.  bf16 activations flip the ReLU mask
+    at ~2 % of the positions (near-zero pre-activations); with a random upstream gradient each
+    flip moves a parameter-gradient sum by a whole |g| (measured 5-20 % of the peak), with this
+    loss the upstream gradient vanishes where the last mask flips, leaving 0.2-5 %.  Bound: 8 %
+    of the peak.  The kernels themselves are pinned tightly, on identical operands, by
+    test_conv_kernels_individually."""
+
+    B, Fin, Tin = 2, 24, 150
+    _, (cnn, blocks, out), (cnn_r, blocks_r, ref) = _conv_ref_and_hip(cuda, B, Fin, Tin, 9)
+    (0.5 * ref.float() ** 2).sum().backward()
+    (0.5 * out.float() ** 2).sum().backward()
+    def rel(a, b):
+        return float((a - b).abs().max()) / max(float(b.abs().max()), 1e-6)
+    tol = 8e-2
+    assert rel(cnn.weight.grad, cnn_r.weight.grad) <= tol
+    assert rel(cnn.bias.grad, cnn_r.bias.grad) <= tol
+    for a, b in zip(blocks, blocks_r):
+        assert rel(a.conv1.weight.grad, b.conv1.weight.grad) <= tol
+        assert rel(a.conv2.weight.grad, b.conv2.weight.grad) <= tol
+        assert rel(a.bn1.weight.grad, b.bn1.weight.grad) <= tol
+        assert rel(a.bn1.bias.grad, b.bn1.bias.grad) <= tol
+        assert rel(a.bn2.weight.grad, b.bn2.weight.grad) <= tol
+        assert rel(a.bn2.bias.grad, b.bn2.bias.grad) <= tol
+        # conv bias before batch-statistics BN: zero gradient (torch returns rounding noise)
+        assert float(a.conv1.bias.grad.abs().max()) == 0.0
+        assert float(b.conv1.bias.grad.abs().max()) <= 1e-3 * float(b.conv1.weight.grad.abs().max()) + 1e-4

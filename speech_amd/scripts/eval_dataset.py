@@ -1,0 +1,49 @@
+"""Batched inference and CER/WER -- same surface as the reference's scripts/eval_dataset.py:19-129
+(``test(dataset_type, batch_size, model, test_loader, beam_decode)``); greedy decoding only (the
+pyctcdecode beam + KenLM path, eval_dataset.py:20-27, is SURVEY section 8f item 3, not built).
+
+    python -m speech_amd.scripts.eval_dataset False synthetic [model.pth]
+"""
+import sys
+
+import torch
+
+from .. import data, decoder, net
+
+
+def test(dataset_type, batch_size, model, test_loader, beam_decode=False, log=print):
+    if beam_decode:
+        raise NotImplementedError("beam search with a KenLM scorer is not part of this build")
+    log("\nevaluating...")
+    model.eval()
+    test_cer, test_wer = [], []
+    with torch.no_grad():
+        for batch in test_loader:
+            spectrograms, labels, label_lengths = batch
+            logits = model(spectrograms.cuda())                       # [B, T', V]
+            # eval_dataset.py:40 takes log_softmax first; the greedy path is invariant to it
+            preds, targets = decoder.greedy_decoder(logits, labels, label_lengths)
+            for tgt, pred in zip(targets, preds):
+                test_cer.append(decoder.cer(tgt, pred))
+                test_wer.append(decoder.wer(tgt, pred))
+    avg_cer = sum(test_cer) / len(test_cer)
+    avg_wer = sum(test_wer) / len(test_wer)
+    log("Test set: Average CER: {:4f} Average WER: {:.4f}\n".format(avg_cer, avg_wer))
+    return avg_cer, avg_wer
+
+
+if __name__ == "__main__":
+    beam_decode = sys.argv[1] == "True"
+    dataset_type = sys.argv[2]
+    model_file = sys.argv[3] if len(sys.argv) > 3 else None
+    hparams = {"batch_size": 64, "n_rnn_layers": 10, "rnn_dim": 512, "dropout": 0.1, "n_vocab": 28,
+               "n_feats": data.N_MELS, "projection_size": 0}
+    model = net.SRModel(hparams["n_rnn_layers"], hparams["rnn_dim"], hparams["n_vocab"], hparams["n_feats"],
+                        hparams["dropout"], hparams["projection_size"], compute_dtype=torch.bfloat16).cuda()
+    if model_file:
+        model.load_checkpoint(torch.load(model_file, map_location="cpu", weights_only=True))
+    if dataset_type != "synthetic":
+        raise SystemExit("only the synthetic corpus is available here (the reference's manifests point at /hd1)")
+    ds = data.SyntheticSorted(256, hparams["batch_size"], max_s=8.0, seed=3)
+    loader = [data.collate_fn(ds[i], "valid") for i in range(len(ds))]
+    test(dataset_type, hparams["batch_size"], model, loader, beam_decode)

@@ -1,0 +1,199 @@
+"""GPU tests of the host-side mirror of the reference interface (net / data / decoder / train /
+scripts) running on the HIP kernels, against the CPU oracle."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import decode as odec
+from oracle import mel as omel
+from oracle import net as onet
+from oracle import text as otext
+
+pytestmark = pytest.mark.gpu
+
+
+def _small_model(cuda, dtype=torch.float32, layers=2, dim=64, vocab=28, seed=0):
+    from speech_amd import net
+    torch.manual_seed(seed)
+    m = net.SRModel(layers, dim, vocab, 80, 0.0, 0, compute_dtype=dtype).to(cuda)
+    with torch.no_grad():
+        for blk in m.resnet_layers:
+            blk.bn2.weight.uniform_(0.5, 1.0)      # the default (0) makes every block the identity
+    return m
+
+
+def test_state_dict_layout_matches_reference_names(cuda):
+    """key names and shapes of net.py's state_dict."""
+    from speech_amd import net
+    m = net.SRModel(10, 512, 28, 80, 0.1, 0)
+    sd = m.state_dict()
+    assert tuple(sd["cnn.weight"].shape) == (32, 1, 3, 3)
+    assert tuple(sd["resnet_layers.2.conv2.weight"].shape) == (32, 32, 3, 5)
+    assert "resnet_layers.0.bn1.num_batches_tracked" in sd
+    assert float(sd["resnet_layers.1.bn2.weight"].abs().max()) == 0.0           # net.py:30
+    assert tuple(sd["sru_layers.rnn_lst.0.weight"].shape) == (1280, 4096)
+    assert tuple(sd["sru_layers.rnn_lst.9.weight"].shape) == (1024, 3072)
+    assert tuple(sd["sru_layers.rnn_lst.3.weight_c"].shape) == (2048,)
+    assert tuple(sd["sru_layers.rnn_lst.3.layer_norm.weight"].shape) == (1024,)
+    assert tuple(sd["classifier.1.weight"].shape) == (29, 1024)
+    assert sum(p.numel() for p in m.parameters()) == 33741184                   # SURVEY "Model facts"
+    # both checkpoint shapes load
+    m.load_checkpoint({"epoch": 1, "model_state_dict": sd, "optimizer_state_dict": {}})
+    m.load_checkpoint(sd)
+
+
+@pytest.mark.parametrize("train", [False, True])
+def test_model_forward_matches_cpu_oracle(cuda, train):
+    """SRModel on the HIP kernels (f32 SRU stack, bf16 conv stack) vs oracle.net on the CPU with the
+    same state_dict.  Tolerance: 5 % of the logit range -- the conv stack keeps bf16 activations."""
+    m = _small_model(cuda)
+    m.train(train)
+    g = torch.Generator().manual_seed(1)
+    spec = torch.rand(2, 1, 80, 121, generator=g) * 3
+    sd = {k: v.detach().cpu().clone() for k, v in m.state_dict().items()}
+    with torch.no_grad():
+        out = m(spec.to(cuda)).float().cpu()
+        ref = onet.forward(sd, spec, 2, 64, training=train)
+    assert out.shape == ref.shape == (2, 61, 29)
+    assert float((out - ref).abs().max()) <= 5e-2 * float(ref.abs().max())
+
+
+def test_model_gradients_match_cpu_oracle(cuda):
+    from speech_amd import ops
+    m = _small_model(cuda, layers=2)
+    m.train()
+    g = torch.Generator().manual_seed(2)
+    spec = torch.rand(2, 1, 80, 101, generator=g) * 3
+    labels = torch.randint(1, 29, (2, 6), generator=g)
+    ll = torch.tensor([6, 4], dtype=torch.int32)
+    sd = {k: v.detach().cpu().clone() for k, v in m.state_dict().items()}
+    logits = m(spec.to(cuda)).float()
+    il = torch.full((2,), logits.shape[1], dtype=torch.int32, device=cuda)
+    loss = ops.ctc_loss(logits, labels.to(cuda), il, ll.to(cuda))
+    loss.backward()
+    ref_loss, ref_grads, _ = onet.loss_and_grads(sd, spec, labels, ll, 2, 64, training=True)
+    assert float(loss) == pytest.approx(float(ref_loss), rel=3e-2)
+    named = dict(m.named_parameters())
+    for k in ["classifier.1.weight", "sru_layers.rnn_lst.1.weight", "sru_layers.rnn_lst.1.weight_c",
+              "sru_layers.rnn_lst.0.weight", "sru_layers.rnn_lst.0.layer_norm.weight", "sru_layers.rnn_lst.0.bias"]:
+        a, b = named[k].grad.cpu(), ref_grads[k]
+        assert float((a - b).abs().max()) <= 8e-2 * float(b.abs().max()) + 1e-7, k
+
+
+def test_flat_adam_matches_torch_adam(cuda):
+    from speech_amd.train import FlatAdam
+    torch.manual_seed(0)
+    ps = [torch.nn.Parameter(torch.randn(n, device=cuda)) for n in (1000, 37, 4096, 3)]
+    qs = [torch.nn.Parameter(p.detach().clone()) for p in ps]
+    opt = FlatAdam(ps, lr=1e-2, weight_decay=0.0)
+    ref = torch.optim.Adam(qs, lr=1e-2)
+    for step in range(5):
+        gs = [torch.randn_like(p) * (10.0 if step == 2 else 0.1) for p in ps]
+        opt.zero_grad()
+        for p, q, gr in zip(ps, qs, gs):
+            p.grad.copy_(gr)
+            q.grad = gr.clone()
+        torch.nn.utils.clip_grad_norm_(qs, 2.0)
+        ref.step()
+        opt.step(max_norm=2.0)
+        for p, q in zip(ps, qs):
+            assert torch.allclose(p, q, rtol=1e-5, atol=1e-6), step
+    # decoupled weight decay: p *= 1 - lr*wd after the Adam update
+    opt2 = FlatAdam([torch.nn.Parameter(torch.ones(8, device=cuda))], lr=0.1, weight_decay=0.5)
+    opt2.zero_grad()
+    opt2.step()
+    assert torch.allclose(opt2.plist[0], torch.full((8,), 0.95, device=cuda))
+
+
+def test_collate_contract_and_specaugment(cuda):
+    """data.collate_fn returns the reference's batch contract; masks follow torchaudio's draw order."""
+    from speech_amd import data, text
+    g = torch.Generator().manual_seed(4)
+    clips = [(torch.randn(1, n, generator=g) * 0.1, s) for n, s in
+             [(8000, "hello world"), (12000, "it's a test"), (4000, "a")]]
+    spec, labels, ll = data.collate_fn(clips, "valid")
+    assert spec.shape == (3, 1, 80, 76) and spec.dtype == torch.float32 and spec.is_cuda
+    assert labels.dtype == torch.int64 and labels.shape == (3, 11) and ll.dtype == torch.int32
+    assert labels[2].tolist() == text.text_to_int("a") + [0] * 10 and ll.tolist() == [11, 11, 1]
+    ref = omel.collate([w for w, _ in clips])
+    assert float((spec.cpu() - ref).abs().max()) <= 1e-4 * float(ref.abs().max())
+    torch.manual_seed(123)
+    spec_t, _, _ = data.collate_fn(clips, "train")
+    torch.manual_seed(123)
+    masks = []
+    for w, _ in clips:   # oracle.mel.mask_params on the same uniform draws, same order
+        tb = 1 + w.numel() // 160
+        u = [float(torch.rand(1)) for _ in range(2)]
+        f0, fw = omel.mask_params(u[0], u[1], 15, 80)
+        u = [float(torch.rand(1)) for _ in range(2)]
+        t0, tw = omel.mask_params(u[0], u[1], 35, tb)
+        masks.append((f0, fw, t0, tw))
+    ref_t = omel.collate([w for w, _ in clips], masks)
+    assert float((spec_t.cpu() - ref_t).abs().max()) <= 1e-4 * float(ref.abs().max())
+    # the transform objects mirror data.spectrogram_transform's shape contract
+    one = data.spectrogram_transform(clips[0][0])
+    assert one.shape == (1, 80, 51)
+
+
+def test_wer_parity_on_1k_synthetic_utterances(cuda):
+    """BASELINE configs[4]: greedy decode of 1000 synthetic utterances; decoded strings, CER and WER
+    identical to the CPU reference path (oracle.decode = decoder.py semantics)."""
+    from speech_amd import decoder, text
+    g = torch.Generator().manual_seed(7)
+    B, T, V = 1000, 200, 29
+    # render a random target alignment + noise so that WER is neither 0 nor 1
+    L = 30
+    labels = torch.randint(1, V, (B, L), generator=g)
+    labels[:, ::5] = 2                                              # spaces -> words
+    ll = torch.randint(10, L + 1, (B,), generator=g).int()
+    scores = torch.randn(B, T, V, generator=g) * 0.8
+    for b in range(B):
+        pos = torch.sort(torch.randperm(T // 2, generator=g)[: int(ll[b])]).values * 2
+        scores[b, :, 0] += 3.2
+        scores[b, pos, labels[b, : int(ll[b])]] += 6.0
+    dec, tgt = decoder.greedy_decoder(scores.to(cuda), labels, ll)
+    rdec, rtgt = odec.greedy_decoder(scores, labels, ll)
+    assert dec == rdec and tgt == rtgt
+    keep = [i for i in range(B) if tgt[i].replace(" ", "") and tgt[i].split()]
+    cer = [decoder.cer(tgt[i], dec[i]) for i in keep]
+    wer = [decoder.wer(tgt[i], dec[i]) for i in keep]
+    rcer = [odec.cer(rtgt[i], rdec[i]) for i in keep]
+    rwer = [odec.wer(rtgt[i], rdec[i]) for i in keep]
+    assert cer == rcer and wer == rwer
+    assert 0.0 < sum(wer) / len(wer) < 1.0
+    assert text.CHARS == otext.CHARS
+
+
+def test_train_step_reduces_loss_bf16(cuda):
+    from speech_amd.train import FlatAdam, train_step
+    m = _small_model(cuda, dtype=torch.bfloat16, layers=2, dim=64)
+    m.train()
+    opt = FlatAdam(m.parameters(), lr=2e-3, weight_decay=1e-3)
+    g = torch.Generator().manual_seed(3)
+    spec = (torch.rand(4, 1, 80, 161, generator=g) * 3).to(cuda)
+    labels = torch.randint(1, 29, (4, 8), generator=g).to(cuda)
+    ll = torch.tensor([8, 6, 5, 3], dtype=torch.int32, device=cuda)
+    losses = [float(train_step(m, opt, spec, labels, ll, 2.0)) for _ in range(12)]
+    assert np.isfinite(losses).all() and losses[-1] < 0.7 * losses[0], losses
+
+
+def test_scripts_predict_and_eval(cuda, tmp_path):
+    import wave
+    from speech_amd import data
+    from speech_amd.scripts import eval_dataset, predict
+    m = _small_model(cuda, layers=1, dim=64)
+    ckpt = tmp_path / "m.pth"
+    torch.save({"epoch": 1, "model_state_dict": m.state_dict(), "optimizer_state_dict": {}}, ckpt)
+    m2 = _small_model(cuda, layers=1, dim=64, seed=5)
+    m2.load_checkpoint(torch.load(ckpt, weights_only=True))
+    m2.eval()
+    pcm = (np.sin(np.arange(16000) * 0.05) * 8000).astype(np.int16)
+    path = str(tmp_path / "a.wav")
+    with wave.open(path, "wb") as f:
+        f.setnchannels(1); f.setsampwidth(2); f.setframerate(16000); f.writeframes(pcm.tobytes())
+    out = predict.predict(path, m2)
+    assert isinstance(out, list) and len(out) == 1 and isinstance(out[0], str)
+    ds = data.SyntheticSorted(8, 4, max_s=2.0, seed=3)
+    loader = [data.collate_fn(ds[i], "valid") for i in range(len(ds))]
+    cer, wer = eval_dataset.test("synthetic", 4, m2, loader, False, log=lambda *a: None)
+    assert cer >= 0 and wer >= 0

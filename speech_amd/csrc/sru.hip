@@ -10,15 +10,20 @@
 // one wave = 64 adjacent channels (coalesced 128/256-byte row segments), and each wave keeps two
 // register batches of UN time steps in flight (load batch n+1 while the serial chain runs over
 // batch n).  U is laid out [T*B][k][2][d] so that each gate plane is contiguous across lanes.
+#include <type_traits>
+
 #include "common.h"
 
 namespace sp {
 
 constexpr float kL2e = 1.4426950408889634f;
 
-__device__ __forceinline__ float sigmoidf_fast(float x) {
-    return __frcp_rn(1.f + exp2f(-x * kL2e));
+// sigmoid on the raw transcendental units (v_exp_f32 / v_rcp_f32, 1 ulp each): the serial chain of
+// the recurrence is c -> fma -> exp -> add -> rcp -> fma, so every instruction on it is latency.
+__device__ __forceinline__ float sigmoid_neg2(float xs) {  // xs = -log2(e) * x
+    return __builtin_amdgcn_rcpf(1.f + __builtin_amdgcn_exp2f(xs));
 }
+__device__ __forceinline__ float sigmoidf_fast(float x) { return sigmoid_neg2(-kL2e * x); }
 
 template <typename T, int K, int UN>
 __global__ __launch_bounds__(64) void sru_fwd_kernel(
@@ -178,6 +183,234 @@ __global__ __launch_bounds__(64) void sru_bwd_kernel(
     atomicAdd(&gbias[D2 + cd], gbr);
 }
 
+
+// ---------------------------------------------------------------------------------------------
+// Loader-ring variants (bf16, d % 128 == 0): the production path.
+//
+// The register-pipelined kernels above are capped by the 64 outstanding vector-memory operations a
+// wave may have: 64 x 128 B per wave x (columns / 64) waves = 4 MB in flight chip-wide whatever the
+// unroll, i.e. ~1.8 TB/s at the observed latency.  Here a workgroup is 2 consumer waves (128
+// columns, one per lane) plus ONE loader wave that only issues LDS-DMA (global_load_lds_dwordx4,
+// 1 KiB per instruction = all four streams of one time step for the 128 columns) into an LDS ring,
+// so the same 64-deep queue holds 64 KiB.  Hand-off per chunk of CH steps: the loader waits with a
+// COUNTED vmcnt for the oldest chunk, all three waves meet at a raw s_barrier, the consumers read
+// that chunk with ds_read while the loader refills the slot the consumers released one chunk ago.
+// Loads past the end of the sequence are clamped re-loads so the count per chunk stays constant.
+// ---------------------------------------------------------------------------------------------
+typedef __attribute__((address_space(1))) const void* gptr_t;
+typedef __attribute__((address_space(3))) void* lptr_t;
+
+__device__ __forceinline__ float lds_bf16(const unsigned char* p) {
+    return __uint_as_float(((uint32_t)*reinterpret_cast<const uint16_t*>(p)) << 16);
+}
+
+template <int K>
+__global__ __launch_bounds__(192) void sru_fwd_ring_kernel(
+    const __hip_bfloat16* __restrict__ U, const __hip_bfloat16* __restrict__ xres,
+    const float* __restrict__ wc, const float* __restrict__ bias, const float* __restrict__ mask,
+    int Tn, int B, int d, __hip_bfloat16* __restrict__ h, float* __restrict__ cst) {
+    constexpr int CH = 8, R = 8, ROW = 1024;
+    __shared__ __attribute__((aligned(16))) unsigned char ring[R * CH * ROW];
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int D2 = 2 * d;
+    const int col0 = blockIdx.x * 128;
+    const int b = col0 / D2, cd0 = col0 - b * D2, dir = cd0 / d;
+    const int nch = (Tn + CH - 1) / CH;
+    const int64_t ustep = (int64_t)B * K * D2, hstep = (int64_t)B * D2;
+
+    if (wave == 2) {
+        // ---- loader: lane = (stream, 16-byte piece) ----
+        const int stream = lane >> 4, c16 = lane & 15;
+        const __hip_bfloat16* base;
+        int64_t step;
+        if (K == 4 || stream < 3) {
+            base = U + (int64_t)b * K * D2 + (int64_t)stream * D2 + cd0 + c16 * 8;
+            step = ustep;
+        } else {
+            base = xres + (int64_t)b * D2 + cd0 + c16 * 8;
+            step = hstep;
+        }
+        auto issue = [&](int c) {
+#pragma unroll
+            for (int s = 0; s < CH; ++s) {
+                const int i = min(c * CH + s, Tn - 1);
+                const int64_t t = dir ? Tn - 1 - i : i;
+                __builtin_amdgcn_global_load_lds((gptr_t)(base + t * step),
+                                                 (lptr_t)(ring + (((c % R) * CH) + s) * ROW), 16, 0, 0);
+            }
+        };
+        for (int c = 0; c < R - 1; ++c) issue(c);
+        for (int c = 0; c < nch; ++c) {
+            asm volatile("s_waitcnt vmcnt(%0)" ::"n"((R - 2) * CH) : "memory");
+            __builtin_amdgcn_s_barrier();
+            issue(c + R - 1);
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // drain before the LDS is released
+        return;
+    }
+    // ---- consumers: one column per lane ----
+    const int cl = wave * 64 + lane;  // column within the workgroup
+    const int cd = cd0 + cl;
+    const float vf = wc[cd], vr = wc[D2 + cd];
+    const float bf = bias[cd], br = bias[D2 + cd];
+    const float m = mask ? mask[(int64_t)b * D2 + cd] : 1.f;
+    __hip_bfloat16* hb = h + (int64_t)b * D2 + cd;
+    float* cb = cst + (int64_t)b * D2 + cd;
+    float c = 0.f;
+    const float nvf = -kL2e * vf, nvr = -kL2e * vr, nbf = -kL2e * bf, nbr = -kL2e * br;
+    auto chunk = [&](int ch, auto guard) {
+        constexpr bool GUARD = decltype(guard)::value;
+        const unsigned char* slot = ring + ((ch % R) * CH) * ROW + cl * 2;
+        float v0[CH], a1[CH], a2[CH], x[CH];
+#pragma unroll
+        for (int s = 0; s < CH; ++s) {  // every LDS read of the chunk up front, off the serial chain
+            const unsigned char* row = slot + s * ROW;
+            v0[s] = lds_bf16(row);
+            a1[s] = fmaf(-kL2e, lds_bf16(row + 256), nbf);
+            a2[s] = fmaf(-kL2e, lds_bf16(row + 512), nbr);
+            x[s] = lds_bf16(row + 768);
+        }
+#pragma unroll
+        for (int s = 0; s < CH; ++s) {
+            const int i = ch * CH + s;
+            if (!GUARD || i < Tn) {
+                const int64_t t = dir ? Tn - 1 - i : i;
+                const float f = sigmoid_neg2(fmaf(nvf, c, a1[s]));
+                const float r = sigmoid_neg2(fmaf(nvr, c, a2[s]));
+                c = fmaf(c - v0[s], f, v0[s]);
+                const float hv = fmaf(fmaf(c, m, -x[s]), r, x[s]);
+                hb[t * hstep] = __float2bfloat16(hv);
+                cb[t * hstep] = c;
+            }
+        }
+    };
+    for (int ch = 0; ch < nch; ++ch) {
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+        if ((ch + 1) * CH <= Tn) chunk(ch, std::false_type{});
+        else chunk(ch, std::true_type{});
+    }
+}
+
+template <int K>
+__global__ __launch_bounds__(192) void sru_bwd_ring_kernel(
+    const __hip_bfloat16* __restrict__ U, const __hip_bfloat16* __restrict__ xres,
+    const float* __restrict__ wc, const float* __restrict__ bias, const float* __restrict__ mask,
+    const float* __restrict__ cst, const __hip_bfloat16* __restrict__ gh, int Tn, int B, int d,
+    __hip_bfloat16* __restrict__ gU, __hip_bfloat16* __restrict__ gxres, float* __restrict__ gwc,
+    float* __restrict__ gbias) {
+    constexpr int CH = 4, R = 8, ROW = 2048;  // row: u0 u1 u2 x' (4 x 256 B) | gh (256 B) | c_prev f32 (512 B)
+    __shared__ __attribute__((aligned(16))) unsigned char ring[R * CH * ROW];
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int D2 = 2 * d;
+    const int col0 = blockIdx.x * 128;
+    const int b = col0 / D2, cd0 = col0 - b * D2, dir = cd0 / d;
+    const int nch = (Tn + CH - 1) / CH;
+    const int64_t ustep = (int64_t)B * K * D2, hstep = (int64_t)B * D2;
+
+    if (wave == 2) {
+        const int stream = lane >> 4, c16 = lane & 15;
+        const __hip_bfloat16* base;
+        int64_t step;
+        if (K == 4 || stream < 3) {
+            base = U + (int64_t)b * K * D2 + (int64_t)stream * D2 + cd0 + c16 * 8;
+            step = ustep;
+        } else {
+            base = xres + (int64_t)b * D2 + cd0 + c16 * 8;
+            step = hstep;
+        }
+        // second instruction: lanes 0-15 gh (bf16, 8 columns each), lanes 16-47 c_prev (f32, 4 columns each)
+        const char* base2 = lane < 16 ? reinterpret_cast<const char*>(gh + (int64_t)b * D2 + cd0 + lane * 8)
+                                      : reinterpret_cast<const char*>(cst + (int64_t)b * D2 + cd0 + (lane - 16) * 4);
+        const int64_t step2 = lane < 16 ? hstep * 2 : hstep * 4;  // bytes
+        auto issue = [&](int c) {
+#pragma unroll
+            for (int s = 0; s < CH; ++s) {
+                const int jr = min(c * CH + s, Tn - 1);    // walk the forward order backwards
+                const int i = Tn - 1 - jr;
+                const int64_t t = dir ? Tn - 1 - i : i;
+                unsigned char* row = ring + (((c % R) * CH) + s) * ROW;
+                __builtin_amdgcn_global_load_lds((gptr_t)(base + t * step), (lptr_t)row, 16, 0, 0);
+                // c_prev: cell state of forward step i-1 (consumer substitutes 0 at i == 0)
+                const int ip = max(i - 1, 0);
+                const int64_t tp = dir ? Tn - 1 - ip : ip;
+                const int64_t t2 = lane < 16 ? t : tp;
+                if (lane < 48)
+                    __builtin_amdgcn_global_load_lds((gptr_t)(base2 + t2 * step2), (lptr_t)(row + 1024), 16, 0, 0);
+            }
+        };
+        for (int c = 0; c < R - 1; ++c) issue(c);
+        for (int c = 0; c < nch; ++c) {
+            asm volatile("s_waitcnt vmcnt(%0)" ::"n"((R - 2) * CH * 2) : "memory");
+            __builtin_amdgcn_s_barrier();
+            issue(c + R - 1);
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        return;
+    }
+    const int cl = wave * 64 + lane;
+    const int cd = cd0 + cl;
+    const float vf = wc[cd], vr = wc[D2 + cd];
+    const float bf = bias[cd], br = bias[D2 + cd];
+    const float m = mask ? mask[(int64_t)b * D2 + cd] : 1.f;
+    __hip_bfloat16* gUb = gU + (int64_t)b * K * D2 + cd;
+    __hip_bfloat16* gXb = (K == 3) ? gxres + (int64_t)b * D2 + cd : nullptr;
+    float gc = 0.f, gvf = 0.f, gvr = 0.f, gbf = 0.f, gbr = 0.f;
+    const float nvf = -kL2e * vf, nvr = -kL2e * vr, nbf = -kL2e * bf, nbr = -kL2e * br;
+    auto chunk = [&](int ch, auto guard) {
+        constexpr bool GUARD = decltype(guard)::value;
+        const unsigned char* slot = ring + ((ch % R) * CH) * ROW;
+        float v0[CH], f_[CH], r_[CH], x[CH], g[CH], cp[CH];
+#pragma unroll
+        for (int s = 0; s < CH; ++s) {  // gates depend only on loaded data: all off the serial chain
+            const unsigned char* row = slot + s * ROW;
+            const int jr = ch * CH + s;
+            v0[s] = lds_bf16(row + cl * 2);
+            const float u1 = lds_bf16(row + 256 + cl * 2), u2 = lds_bf16(row + 512 + cl * 2);
+            x[s] = lds_bf16(row + 768 + cl * 2);
+            g[s] = lds_bf16(row + 1024 + cl * 2);
+            cp[s] = *reinterpret_cast<const float*>(row + 1280 + cl * 4);
+            if (jr >= Tn - 1) cp[s] = 0.f;  // forward step 0 has no predecessor
+            f_[s] = sigmoid_neg2(fmaf(nvf, cp[s], fmaf(-kL2e, u1, nbf)));
+            r_[s] = sigmoid_neg2(fmaf(nvr, cp[s], fmaf(-kL2e, u2, nbr)));
+        }
+#pragma unroll
+        for (int s = 0; s < CH; ++s) {
+            const int jr = ch * CH + s;
+            if (!GUARD || jr < Tn) {
+                const int i = Tn - 1 - jr;
+                const int64_t t = dir ? Tn - 1 - i : i;
+                const float f = f_[s], r = r_[s];
+                const float cc = fmaf(cp[s] - v0[s], f, v0[s]);
+                const float gr = g[s] * fmaf(cc, m, -x[s]);
+                const float gx = g[s] * (1.f - r);
+                const float gct = fmaf(g[s] * r, m, gc);
+                const float dr = gr * r * (1.f - r);
+                const float g0 = gct * (1.f - f);
+                const float df = gct * (cp[s] - v0[s]) * f * (1.f - f);
+                gc = fmaf(gct, f, fmaf(df, vf, dr * vr));
+                gvf = fmaf(df, cp[s], gvf); gvr = fmaf(dr, cp[s], gvr); gbf += df; gbr += dr;
+                __hip_bfloat16* gp = gUb + t * ustep;
+                gp[0] = __float2bfloat16(g0);
+                gp[D2] = __float2bfloat16(df);
+                gp[2 * D2] = __float2bfloat16(dr);
+                if (K == 3) gXb[t * hstep] = __float2bfloat16(gx);
+                else gp[3 * D2] = __float2bfloat16(gx);
+            }
+        }
+    };
+    for (int ch = 0; ch < nch; ++ch) {
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+        if ((ch + 1) * CH <= Tn) chunk(ch, std::false_type{});
+        else chunk(ch, std::true_type{});
+    }
+    atomicAdd(&gwc[cd], gvf);
+    atomicAdd(&gwc[D2 + cd], gvr);
+    atomicAdd(&gbias[cd], gbf);
+    atomicAdd(&gbias[D2 + cd], gbr);
+}
+
 template <typename T>
 static int sru_fwd_t(const void* U, const void* xres, const float* wc, const float* bias,
                      const float* mask, int Tn, int B, int d, int k, void* h, float* c, hipStream_t s) {
@@ -227,6 +460,17 @@ extern "C" int sp_sru_fwd(const void* U, const void* xres, const float* wc, cons
     SP_CHECK_ARG(U && wc && bias && h && c && (k == 4 || xres), "sp_sru_fwd: null pointer");
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
     if (dtype == SP_F32) return sru_fwd_t<float>(U, xres, wc, bias, mask, T, B, d, k, h, c, s);
+    if (d % 128 == 0) {  // loader-ring path
+        typedef __hip_bfloat16 bf;
+        const int blocks = B * 2 * d / 128;
+        if (k == 3)
+            hipLaunchKernelGGL((sru_fwd_ring_kernel<3>), dim3(blocks), dim3(192), 0, s, (const bf*)U, (const bf*)xres,
+                               wc, bias, mask, T, B, d, (bf*)h, c);
+        else
+            hipLaunchKernelGGL((sru_fwd_ring_kernel<4>), dim3(blocks), dim3(192), 0, s, (const bf*)U, (const bf*)xres,
+                               wc, bias, mask, T, B, d, (bf*)h, c);
+        return check_launch("sru_fwd_ring_kernel");
+    }
     return sru_fwd_t<__hip_bfloat16>(U, xres, wc, bias, mask, T, B, d, k, h, c, s);
 }
 
@@ -243,5 +487,16 @@ extern "C" int sp_sru_bwd(const void* U, const void* xres, const float* wc, cons
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
     if (dtype == SP_F32)
         return sru_bwd_t<float>(U, xres, wc, bias, mask, c, gh, T, B, d, k, gU, gxres, gwc, gbias, s);
+    if (d % 128 == 0) {  // loader-ring path
+        typedef __hip_bfloat16 bf;
+        const int blocks = B * 2 * d / 128;
+        if (k == 3)
+            hipLaunchKernelGGL((sru_bwd_ring_kernel<3>), dim3(blocks), dim3(192), 0, s, (const bf*)U, (const bf*)xres,
+                               wc, bias, mask, c, (const bf*)gh, T, B, d, (bf*)gU, (bf*)gxres, gwc, gbias);
+        else
+            hipLaunchKernelGGL((sru_bwd_ring_kernel<4>), dim3(blocks), dim3(192), 0, s, (const bf*)U, (const bf*)xres,
+                               wc, bias, mask, c, (const bf*)gh, T, B, d, (bf*)gU, (bf*)gxres, gwc, gbias);
+        return check_launch("sru_bwd_ring_kernel");
+    }
     return sru_bwd_t<__hip_bfloat16>(U, xres, wc, bias, mask, c, gh, T, B, d, k, gU, gxres, gwc, gbias, s);
 }

@@ -308,10 +308,12 @@ def _sru_ref(U, x, wc, bias, mask, d):
 
 
 @pytest.mark.parametrize("k", [3, 4])
-@pytest.mark.parametrize("dtype,tol", [(torch.float32, 2e-5), (torch.bfloat16, 2e-2)])
-def test_sru_recurrence_fwd_bwd(cuda, k, dtype, tol):
+@pytest.mark.parametrize("dtype,tol,T,d", [(torch.float32, 2e-5, 37, 64), (torch.bfloat16, 2e-2, 37, 64),
+                                           (torch.bfloat16, 2e-2, 131, 128),   # loader-ring kernels
+                                           (torch.bfloat16, 2e-2, 7, 256), (torch.bfloat16, 2e-2, 64, 128)])
+def test_sru_recurrence_fwd_bwd(cuda, k, dtype, tol, T, d):
     from speech_amd import ops
-    T, B, d = 37, 3, 64
+    B = 3
     U, x, wc, bias, mask = _sru_inputs(T, B, d, k, 11 + k, dtype)
     Ud = U.to(cuda).requires_grad_(True)
     xd = x.to(cuda).requires_grad_(True) if x is not None else None

@@ -180,6 +180,19 @@ int sp_block_out(const void* y2, const float* coef, const void* x, int B, int F,
 int sp_block_bwd_in(const void* gz, const void* z, int64_t zsb, int64_t zsf, int64_t zst,
                     const void* y2, int B, int F, int T, void* gpre, float* sums, void* stream);
 
+/* ---------------------------------------------------------------------------------------
+ * Row LayerNorm.  Replaces the layer norms of net.py:61-76 (sru.SRU(layer_norm=True) on every
+ * layer input; nn.LayerNorm before the classifier).  x, y, gy, gx, gres: [M][N] of dtype
+ * (SP_F32 / SP_BF16), N % 8 == 0, N <= 2048; gamma, beta, mean, rstd, dgamma, dbeta f32.
+ * Backward: gx = LN'(gy) (+ gres if not NULL: the SRU highway's residual gradient);
+ * dgamma / dbeta are ACCUMULATED (caller zeroes).
+ * --------------------------------------------------------------------------------------- */
+int sp_layernorm_fwd(const void* x, const float* gamma, const float* beta, int64_t M, int N, float eps,
+                     int dtype, void* y, float* mean, float* rstd, void* stream);
+int sp_layernorm_bwd(const void* gy, const void* x, const float* mean, const float* rstd,
+                     const float* gamma, const void* gres, int64_t M, int N, int dtype, void* gx,
+                     float* dgamma, float* dbeta, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -1,0 +1,216 @@
+// Row LayerNorm forward / backward for the SRU stack and classifier (net.py:61-76 of the reference:
+// sru.SRU(layer_norm=True) normalises each layer's input, nn.LayerNorm precedes the classifier).
+// One wave per row, the row lives in registers (<= 4 x 8 elements per lane, N <= 2048, N % 8 == 0),
+// 16-byte loads/stores, two-pass statistics in f32.  The backward fuses the residual gradient that
+// the SRU highway sends around the projection (gx = LN'(gy) + gres) and keeps per-lane partial
+// sums of dgamma/dbeta over all rows a wave visits; one LDS reduction and one set of float atomics
+// per block at the end.  HBM-bound: forward reads and writes the activation once.
+#include "common.h"
+
+namespace sp {
+
+constexpr int kLnMaxChunks = 4;
+
+template <typename T> struct Vec8;
+template <> struct Vec8<__hip_bfloat16> {
+    static __device__ __forceinline__ void ld(const __hip_bfloat16* p, float (&f)[8]) {
+        const uint4 v = *reinterpret_cast<const uint4*>(p);
+        const uint32_t w[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            f[2 * i] = __uint_as_float(w[i] << 16);
+            f[2 * i + 1] = __uint_as_float(w[i] & 0xFFFF0000u);
+        }
+    }
+    static __device__ __forceinline__ void st(__hip_bfloat16* p, const float (&f)[8]) {
+        uint32_t w[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const uint32_t lo = __builtin_bit_cast(unsigned short, __float2bfloat16(f[2 * i]));
+            const uint32_t hi = __builtin_bit_cast(unsigned short, __float2bfloat16(f[2 * i + 1]));
+            w[i] = lo | (hi << 16);
+        }
+        *reinterpret_cast<uint4*>(p) = make_uint4(w[0], w[1], w[2], w[3]);
+    }
+};
+template <> struct Vec8<float> {
+    static __device__ __forceinline__ void ld(const float* p, float (&f)[8]) {
+        const float4 a = *reinterpret_cast<const float4*>(p), b = *reinterpret_cast<const float4*>(p + 4);
+        f[0] = a.x; f[1] = a.y; f[2] = a.z; f[3] = a.w; f[4] = b.x; f[5] = b.y; f[6] = b.z; f[7] = b.w;
+    }
+    static __device__ __forceinline__ void st(float* p, const float (&f)[8]) {
+        *reinterpret_cast<float4*>(p) = make_float4(f[0], f[1], f[2], f[3]);
+        *reinterpret_cast<float4*>(p + 4) = make_float4(f[4], f[5], f[6], f[7]);
+    }
+};
+
+template <typename T>
+__global__ __launch_bounds__(256) void ln_fwd_kernel(const T* __restrict__ x, const float* __restrict__ gamma,
+                                                     const float* __restrict__ beta, int64_t M, int N, float eps,
+                                                     T* __restrict__ y, float* __restrict__ mean_out,
+                                                     float* __restrict__ rstd_out) {
+    const int lane = threadIdx.x & 63;
+    const int nchunk = N >> 3;
+    const float inv_n = 1.f / (float)N;
+    for (int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6); row < M; row += (int64_t)gridDim.x * 4) {
+        const T* xr = x + row * N;
+        float v[kLnMaxChunks][8];
+        float s = 0.f;
+#pragma unroll
+        for (int c = 0; c < kLnMaxChunks; ++c) {
+            const int ch = lane + 64 * c;
+            if (ch < nchunk) {
+                Vec8<T>::ld(xr + ch * 8, v[c]);
+#pragma unroll
+                for (int j = 0; j < 8; ++j) s += v[c][j];
+            }
+        }
+        const float mean = wave_sum(s) * inv_n;
+        float q = 0.f;
+#pragma unroll
+        for (int c = 0; c < kLnMaxChunks; ++c)
+            if (lane + 64 * c < nchunk) {
+#pragma unroll
+                for (int j = 0; j < 8; ++j) { const float dlt = v[c][j] - mean; q += dlt * dlt; }
+            }
+        const float rstd = rsqrtf(wave_sum(q) * inv_n + eps);
+        if (lane == 0) { mean_out[row] = mean; rstd_out[row] = rstd; }
+#pragma unroll
+        for (int c = 0; c < kLnMaxChunks; ++c) {
+            const int ch = lane + 64 * c;
+            if (ch < nchunk) {
+                float o[8];
+#pragma unroll
+                for (int j = 0; j < 8; ++j) o[j] = (v[c][j] - mean) * rstd * gamma[ch * 8 + j] + beta[ch * 8 + j];
+                Vec8<T>::st(y + row * N + ch * 8, o);
+            }
+        }
+    }
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void ln_bwd_kernel(const T* __restrict__ gy, const T* __restrict__ x,
+                                                     const float* __restrict__ mean_in,
+                                                     const float* __restrict__ rstd_in,
+                                                     const float* __restrict__ gamma, const T* __restrict__ gres,
+                                                     int64_t M, int N, T* __restrict__ gx,
+                                                     float* __restrict__ dgamma, float* __restrict__ dbeta) {
+    extern __shared__ float red[];  // [4 waves][2][N]
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int nchunk = N >> 3;
+    const float inv_n = 1.f / (float)N;
+    float dg[kLnMaxChunks][8], db[kLnMaxChunks][8], gm[kLnMaxChunks][8];
+#pragma unroll
+    for (int c = 0; c < kLnMaxChunks; ++c)
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            dg[c][j] = 0.f; db[c][j] = 0.f;
+            const int ch = lane + 64 * c;
+            gm[c][j] = ch < nchunk ? gamma[ch * 8 + j] : 0.f;
+        }
+    for (int64_t row = (int64_t)blockIdx.x * 4 + wave; row < M; row += (int64_t)gridDim.x * 4) {
+        const float mean = mean_in[row], rstd = rstd_in[row];
+        float g[kLnMaxChunks][8], xh[kLnMaxChunks][8];
+        float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+        for (int c = 0; c < kLnMaxChunks; ++c) {
+            const int ch = lane + 64 * c;
+            if (ch < nchunk) {
+                Vec8<T>::ld(gy + row * N + ch * 8, g[c]);
+                Vec8<T>::ld(x + row * N + ch * 8, xh[c]);
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    xh[c][j] = (xh[c][j] - mean) * rstd;
+                    dg[c][j] += g[c][j] * xh[c][j];
+                    db[c][j] += g[c][j];
+                    g[c][j] *= gm[c][j];            // d/dxhat
+                    s1 += g[c][j];
+                    s2 += g[c][j] * xh[c][j];
+                }
+            }
+        }
+        const float c1 = wave_sum(s1) * inv_n, c2 = wave_sum(s2) * inv_n;
+#pragma unroll
+        for (int c = 0; c < kLnMaxChunks; ++c) {
+            const int ch = lane + 64 * c;
+            if (ch < nchunk) {
+                float o[8];
+                if (gres) Vec8<T>::ld(gres + row * N + ch * 8, o);
+                else {
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) o[j] = 0.f;
+                }
+#pragma unroll
+                for (int j = 0; j < 8; ++j) o[j] += rstd * (g[c][j] - c1 - xh[c][j] * c2);
+                Vec8<T>::st(gx + row * N + ch * 8, o);
+            }
+        }
+    }
+    // block reduction of the parameter gradients, then one atomic per column per block
+#pragma unroll
+    for (int c = 0; c < kLnMaxChunks; ++c) {
+        const int ch = lane + 64 * c;
+        if (ch < nchunk) {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                red[(wave * 2 + 0) * N + ch * 8 + j] = dg[c][j];
+                red[(wave * 2 + 1) * N + ch * 8 + j] = db[c][j];
+            }
+        }
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < N; i += 256) {
+        atomicAdd(dgamma + i, red[0 * N + i] + red[2 * N + i] + red[4 * N + i] + red[6 * N + i]);
+        atomicAdd(dbeta + i, red[1 * N + i] + red[3 * N + i] + red[5 * N + i] + red[7 * N + i]);
+    }
+}
+
+static int ln_check(const char* who, int64_t M, int N, int dtype) {
+    SP_CHECK_ARG(M >= 0 && N >= 8 && N % 8 == 0 && N <= 512 * kLnMaxChunks,
+                 "%s: N=%d must be a multiple of 8 in [8, %d]", who, N, 512 * kLnMaxChunks);
+    SP_CHECK_ARG(dtype == SP_F32 || dtype == SP_BF16, "%s: dtype %d not supported (f32, bf16)", who, dtype);
+    return SP_OK;
+}
+
+}  // namespace sp
+
+using namespace sp;
+
+extern "C" int sp_layernorm_fwd(const void* x, const float* gamma, const float* beta, int64_t M, int N, float eps,
+                                int dtype, void* y, float* mean, float* rstd, void* stream) {
+    int rc = ln_check("sp_layernorm_fwd", M, N, dtype);
+    if (rc) return rc;
+    if (M == 0) return SP_OK;
+    SP_CHECK_ARG(x && gamma && beta && y && mean && rstd, "sp_layernorm_fwd: null pointer");
+    int64_t blocks = (M + 3) / 4;
+    if (blocks > 4096) blocks = 4096;
+    hipStream_t s = (hipStream_t)stream;
+    if (dtype == SP_F32)
+        hipLaunchKernelGGL((ln_fwd_kernel<float>), dim3((int)blocks), dim3(256), 0, s, (const float*)x, gamma, beta, M, N,
+                           eps, (float*)y, mean, rstd);
+    else
+        hipLaunchKernelGGL((ln_fwd_kernel<__hip_bfloat16>), dim3((int)blocks), dim3(256), 0, s,
+                           (const __hip_bfloat16*)x, gamma, beta, M, N, eps, (__hip_bfloat16*)y, mean, rstd);
+    return check_launch("ln_fwd_kernel");
+}
+
+extern "C" int sp_layernorm_bwd(const void* gy, const void* x, const float* mean, const float* rstd,
+                                const float* gamma, const void* gres, int64_t M, int N, int dtype, void* gx,
+                                float* dgamma, float* dbeta, void* stream) {
+    int rc = ln_check("sp_layernorm_bwd", M, N, dtype);
+    if (rc) return rc;
+    if (M == 0) return SP_OK;
+    SP_CHECK_ARG(gy && x && mean && rstd && gamma && gx && dgamma && dbeta, "sp_layernorm_bwd: null pointer");
+    int64_t blocks = (M + 3) / 4;
+    if (blocks > 512) blocks = 512;
+    const size_t lds = (size_t)8 * N * sizeof(float);
+    hipStream_t s = (hipStream_t)stream;
+    if (dtype == SP_F32)
+        hipLaunchKernelGGL((ln_bwd_kernel<float>), dim3((int)blocks), dim3(256), lds, s, (const float*)gy,
+                           (const float*)x, mean, rstd, gamma, (const float*)gres, M, N, (float*)gx, dgamma, dbeta);
+    else
+        hipLaunchKernelGGL((ln_bwd_kernel<__hip_bfloat16>), dim3((int)blocks), dim3(256), lds, s,
+                           (const __hip_bfloat16*)gy, (const __hip_bfloat16*)x, mean, rstd, gamma,
+                           (const __hip_bfloat16*)gres, M, N, (__hip_bfloat16*)gx, dgamma, dbeta);
+    return check_launch("ln_bwd_kernel");
+}

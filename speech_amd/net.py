@@ -103,15 +103,14 @@ class SRUCell(nn.Module):
 
     def forward(self, x):
         T, B, n_in = x.shape
-        k, d = self.num_matrices, self.hidden_size
+        d = self.hidden_size
         ln = self.layer_norm
-        xn = F.layer_norm(x, (n_in,), self._ln_vec(ln.weight, x.dtype), self._ln_vec(ln.bias, x.dtype), ln.eps)
-        U = (xn.reshape(T * B, n_in) @ self.kernel_weight(x.dtype)).view(T, B, k, 2, d)
         mask = None
         if self.training and self.dropout > 0:
             keep = 1.0 - self.dropout
             mask = torch.bernoulli(torch.full((B, 2 * d), keep, device=x.device)) / keep
-        return ops.sru_recurrence(U, x if k == 3 else None, self.weight_c, self.bias, mask, d)
+        return ops.sru_layer(x, self._ln_vec(ln.weight, torch.float32), self._ln_vec(ln.bias, torch.float32),
+                             self.kernel_weight(x.dtype), self.weight_c, self.bias, mask, d, ln.eps)
 
 
 class SRU(nn.Module):
@@ -156,7 +155,7 @@ class SRModel(nn.Module):
         x, _ = self.sru_layers(x.to(cd))
         x = x.transpose(0, 1).contiguous()  # [B, T', 2*rnn_dim]
         ln, lin = self.classifier[0], self.classifier[1]
-        x = F.layer_norm(x, (x.shape[-1],), ln.weight.to(cd), ln.bias.to(cd), ln.eps)
+        x = ops.layer_norm(x, ln.weight, ln.bias, ln.eps)
         return x @ lin.weight.to(cd).t()
 
     def load_checkpoint(self, obj):

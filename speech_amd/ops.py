@@ -265,3 +265,92 @@ class _SRURecurrenceFn(torch.autograd.Function):
 
 def sru_recurrence(U, xres, wc, bias, mask, d):
     return _SRURecurrenceFn.apply(U, xres, wc, bias, mask, d)
+
+
+# ------------------------------------------------------------------------------------------
+# LayerNorm and the fused SRU layer (net.py:61-76)
+# ------------------------------------------------------------------------------------------
+def layernorm_fwd(x2d, gamma, beta, eps):
+    M, N = x2d.shape
+    y = torch.empty_like(x2d)
+    mean = torch.empty(M, dtype=torch.float32, device=x2d.device)
+    rstd = torch.empty(M, dtype=torch.float32, device=x2d.device)
+    with torch.cuda.device(x2d.device):
+        check(lib().sp_layernorm_fwd(ptr(x2d), ptr(gamma), ptr(beta), M, N, float(eps), _lib.dtype_code(x2d),
+                                     ptr(y), ptr(mean), ptr(rstd), stream_ptr()), "sp_layernorm_fwd")
+    return y, mean, rstd
+
+
+def layernorm_bwd(gy2d, x2d, mean, rstd, gamma, gres2d=None):
+    M, N = x2d.shape
+    gx = torch.empty_like(x2d)
+    dgamma = torch.zeros(N, dtype=torch.float32, device=x2d.device)
+    dbeta = torch.zeros(N, dtype=torch.float32, device=x2d.device)
+    with torch.cuda.device(x2d.device):
+        check(lib().sp_layernorm_bwd(ptr(gy2d), ptr(x2d), ptr(mean), ptr(rstd), ptr(gamma), ptr(gres2d), M, N,
+                                     _lib.dtype_code(x2d), ptr(gx), ptr(dgamma), ptr(dbeta), stream_ptr()),
+              "sp_layernorm_bwd")
+    return gx, dgamma, dbeta
+
+
+class _LayerNormFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, gamma, beta, eps):
+        x2 = x.contiguous().view(-1, x.shape[-1])
+        g32, b32 = gamma.detach().float().contiguous(), beta.detach().float().contiguous()
+        y, mean, rstd = layernorm_fwd(x2, g32, b32, eps)
+        ctx.save_for_backward(x2, mean, rstd, g32)
+        ctx.pdt = (gamma.dtype, beta.dtype)
+        return y.view(x.shape)
+
+    @staticmethod
+    def backward(ctx, gy):
+        x2, mean, rstd, g32 = ctx.saved_tensors
+        gx, dg, db = layernorm_bwd(gy.contiguous().view(x2.shape).to(x2.dtype), x2, mean, rstd, g32)
+        return gx.view(gy.shape), dg.to(ctx.pdt[0]), db.to(ctx.pdt[1]), None
+
+
+def layer_norm(x, gamma, beta, eps=1e-5):
+    return _LayerNormFn.apply(x, gamma, beta, eps)
+
+
+class _SRULayerFn(torch.autograd.Function):
+    """One SRU layer: LayerNorm (HIP) -> projection GEMM (library) -> recurrence (HIP), with a
+    hand-ordered backward: recurrence backward, the two GEMMs, LayerNorm backward fused with the
+    highway's residual gradient.  x [T,B,n_in]; ln_w/ln_b [n_in] (already in the input's feature
+    order); wk [n_in, k*2*d] in the kernels' (k, dir, channel) column order and x's dtype."""
+
+    @staticmethod
+    def forward(ctx, x, ln_w, ln_b, wk, wc, bias, mask, d, eps):
+        T, B, n_in = x.shape
+        k = wk.shape[1] // (2 * d)
+        x2 = x.contiguous().view(T * B, n_in)
+        g32, b32 = ln_w.detach().float().contiguous(), ln_b.detach().float().contiguous()
+        xn, mean, rstd = layernorm_fwd(x2, g32, b32, eps)
+        wk = wk.contiguous()
+        U = torch.mm(xn, wk)
+        wc32, bs32 = wc.detach().float().contiguous(), bias.detach().float().contiguous()
+        xr = x2 if k == 3 else None
+        h, c = sru_fwd(U, xr, wc32, bs32, mask, T, B, d, k)
+        ctx.save_for_backward(x2, xn, mean, rstd, g32, wk, U, wc32, bs32, mask, c)
+        ctx.dims = (T, B, d, k, n_in)
+        ctx.pdt = (ln_w.dtype, ln_b.dtype, wc.dtype, bias.dtype)
+        return h
+
+    @staticmethod
+    def backward(ctx, gh):
+        x2, xn, mean, rstd, g32, wk, U, wc32, bs32, mask, c = ctx.saved_tensors
+        T, B, d, k, n_in = ctx.dims
+        gh = gh.contiguous().to(x2.dtype)
+        gU, gxres, gwc, gbias = sru_bwd(U, x2 if k == 3 else None, wc32, bs32, mask, c, gh, T, B, d, k)
+        gU2 = gU.view(T * B, -1)
+        gwk = torch.mm(xn.t(), gU2)
+        gxn = torch.mm(gU2, wk.t())
+        gx, dg, db = layernorm_bwd(gxn, x2, mean, rstd, g32, gxres.view(T * B, n_in) if k == 3 else None)
+        p = ctx.pdt
+        return (gx.view(T, B, n_in), dg.to(p[0]), db.to(p[1]), gwk, gwc.to(p[2]), gbias.to(p[3]),
+                None, None, None)
+
+
+def sru_layer(x, ln_w, ln_b, wk, wc, bias, mask, d, eps=1e-5):
+    return _SRULayerFn.apply(x, ln_w, ln_b, wk, wc, bias, mask, d, eps)

@@ -512,3 +512,27 @@ def test_conv_stack_backward(cuda):
         # conv bias before batch-statistics BN: zero gradient (torch returns rounding noise)
         assert float(a.conv1.bias.grad.abs().max()) == 0.0
         assert float(b.conv1.bias.grad.abs().max()) <= 1e-3 * float(b.conv1.weight.grad.abs().max()) + 1e-4
+
+
+# =============================================================================== layer norm
+@pytest.mark.parametrize("dtype,tol", [(torch.float32, 1e-5), (torch.bfloat16, 1.5e-2)])
+@pytest.mark.parametrize("shape", [(37, 1024), (5, 1280), (130, 64), (3, 2048)])
+def test_layernorm_fwd_bwd(cuda, dtype, tol, shape):
+    from speech_amd import ops
+    M, N = shape
+    g = torch.Generator().manual_seed(M + N)
+    x = (torch.randn(M, N, generator=g) * 2 + 0.5).to(dtype)
+    w, b = torch.rand(N, generator=g) + 0.5, torch.randn(N, generator=g) * 0.2
+    gy = torch.randn(M, N, generator=g).to(dtype)
+    xd = x.to(cuda).requires_grad_(True)
+    wd, bd = w.to(cuda).requires_grad_(True), b.to(cuda).requires_grad_(True)
+    y = ops.layer_norm(xd, wd, bd)
+    y.backward(gy.to(cuda))
+    xr = x.double().requires_grad_(True)
+    wr, br = w.double().requires_grad_(True), b.double().requires_grad_(True)
+    yr = torch.nn.functional.layer_norm(xr, (N,), wr, br)
+    yr.backward(gy.double())
+    def close(a, b_, what):
+        a, b_ = a.detach().cpu().double(), b_.detach()
+        assert float((a - b_).abs().max()) <= tol * max(1.0, float(b_.abs().max())), what
+    close(y, yr, "y"); close(xd.grad, xr.grad, "gx"); close(wd.grad, wr.grad, "dgamma"); close(bd.grad, br.grad, "dbeta")

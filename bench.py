@@ -89,7 +89,8 @@ def kernel_rooflines(args, model, wav, offs, labels, lens, Lmax, V, iters):
     ms = time_kernel(lambda: ops.melspec(wav, offs, masks=masks, out=spec_buf), iters)
     by = 4.0 * B * N + 4.0 * 80 * B * T
     out["melspec_kernel"] = {"bound": "hbm", "achieved": by / ms / 1e6, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                             "frac": by / ms / 1e6 / HBM_PEAK_GBS, "ms": ms, "algorithmic_bytes": by}
+                             "frac": by / ms / 1e6 / HBM_PEAK_GBS, "ms": ms, "algorithmic_bytes": by,
+                             "launches_per_step": 1}
     # CTC: scores read + grad write + lattice write/read (2*4*sum T'*S_b)
     Tp = (T - 1) // 2 + 1
     logits = torch.randn(B, Tp, V, device=dev) * 3
@@ -99,13 +100,13 @@ def kernel_rooflines(args, model, wav, offs, labels, lens, Lmax, V, iters):
     by = 2 * 4.0 * Tp * B * V + 2 * 4.0 * Tp * S
     out["ctc_fwd_bwd(3 kernels)"] = {"bound": "hbm", "achieved": by / ms / 1e6, "peak": HBM_PEAK_GBS,
                                      "unit": "GB/s", "frac": by / ms / 1e6 / HBM_PEAK_GBS, "ms": ms,
-                                     "algorithmic_bytes": by}
+                                     "algorithmic_bytes": by, "launches_per_step": 1}
     # decode: scores read + ids write
     ms = time_kernel(lambda: ops.greedy_decode_ids(logits), iters)
     by = 4.0 * B * Tp * V + 4.0 * B * Tp
     out["greedy_decode_kernel"] = {"bound": "hbm", "achieved": by / ms / 1e6, "peak": HBM_PEAK_GBS,
                                    "unit": "GB/s", "frac": by / ms / 1e6 / HBM_PEAK_GBS, "ms": ms,
-                                   "algorithmic_bytes": by}
+                                   "algorithmic_bytes": by, "launches_per_step": 0}   # eval path only
     # SRU recurrence forward, one k=3 layer: U + xres read, h + c written
     d = 512
     e = 2 if args.dtype == "bf16" else 4
@@ -117,13 +118,15 @@ def kernel_rooflines(args, model, wav, offs, labels, lens, Lmax, V, iters):
     ms = time_kernel(lambda: ops.sru_fwd(U, xr, wc, bias, None, Tp, B, d, 3), iters)
     by = Tp * B * 2 * d * (3 * e + e + e + 4.0)
     out["sru_fwd_kernel"] = {"bound": "hbm", "achieved": by / ms / 1e6, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                             "frac": by / ms / 1e6 / HBM_PEAK_GBS, "ms": ms, "algorithmic_bytes": by}
+                             "frac": by / ms / 1e6 / HBM_PEAK_GBS, "ms": ms, "algorithmic_bytes": by,
+                             "launches_per_step": 10}
     h, c = ops.sru_fwd(U, xr, wc, bias, None, Tp, B, d, 3)
     gh = torch.randn_like(h)
     ms = time_kernel(lambda: ops.sru_bwd(U, xr, wc, bias, None, c, gh, Tp, B, d, 3), iters)
     by = Tp * B * 2 * d * (3 * e + e + e + 4.0 + 3 * e + e)
     out["sru_bwd_kernel"] = {"bound": "hbm", "achieved": by / ms / 1e6, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                             "frac": by / ms / 1e6 / HBM_PEAK_GBS, "ms": ms, "algorithmic_bytes": by}
+                             "frac": by / ms / 1e6 / HBM_PEAK_GBS, "ms": ms, "algorithmic_bytes": by,
+                             "launches_per_step": 10}
     return out
 
 
@@ -228,7 +231,8 @@ def main():
         }
         if world == 1:
             ks = kernel_rooflines(args, model, wav, offs, labels, lens, Lmax, V, args.kernel_iters)
-            dom = max(ks, key=lambda k: ks[k]["ms"])
+            # dominant = the hand-written kernel with the largest share of the training step
+            dom = max(ks, key=lambda k: ks[k]["ms"] * ks[k]["launches_per_step"])
             r = dict(ks[dom])
             r["kernel"] = dom
             r["traffic"] = None

@@ -180,6 +180,16 @@ int sp_block_out(const void* y2, const float* coef, const void* x, int B, int F,
 int sp_block_bwd_in(const void* gz, const void* z, int64_t zsb, int64_t zsf, int64_t zst,
                     const void* y2, int B, int F, int T, void* gpre, float* sums, void* stream);
 
+/* Projection-weight layout conversion around the SRU projection GEMM (net.py:61-72; the sru
+ * package stores weight[n_in][dir][d][k]).  sp_sru_pack_w: f32 state_dict weight -> Wk[n_in][k][dir][d]
+ * in dtype (SP_F32 / SP_BF16), rows re-ordered from c*F + f to f*C + c (C = 1: unchanged; F = n_in/C)
+ * -- the order the conv stack hands its features over in (net.py:81-83).  sp_sru_unpack_dw: the
+ * inverse for the gradient, summing S split-K partials [S][n_in][k][dir][d] of dtype into f32
+ * dweight[n_in][dir][d][k] (overwritten). */
+int sp_sru_pack_w(const float* weight, int n_in, int d, int k, int C, int dtype, void* out, void* stream);
+int sp_sru_unpack_dw(const void* partials, int S, int n_in, int d, int k, int C, int dtype,
+                     float* dweight, void* stream);
+
 /* ---------------------------------------------------------------------------------------
  * Row LayerNorm.  Replaces the layer norms of net.py:61-76 (sru.SRU(layer_norm=True) on every
  * layer input; nn.LayerNorm before the classifier).  x, y, gy, gx, gres: [M][N] of dtype

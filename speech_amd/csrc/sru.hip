@@ -500,3 +500,86 @@ extern "C" int sp_sru_bwd(const void* U, const void* xres, const float* wc, cons
     }
     return sru_bwd_t<__hip_bfloat16>(U, xres, wc, bias, mask, c, gh, T, B, d, k, gU, gxres, gwc, gbias, s);
 }
+
+// ----------------------------------------------------------------------------------------------
+// Projection-weight layout conversion.  The state_dict keeps the sru package's layout
+// weight[n_in][dir][d][k] (f32, rows in the reference's feature order c*F + f); the kernels and the
+// projection GEMM use Wk[n_in'][k][dir][d] in the activation dtype with rows in the activations'
+// order f*C + c (C = 1: same order).  One thread per (row, dir, channel): k contiguous floats on
+// the state_dict side, k plane-strided elements (coalesced across channels) on the kernel side.
+// ----------------------------------------------------------------------------------------------
+namespace sp {
+template <typename T, int K>
+__global__ __launch_bounds__(256) void sru_pack_w_kernel(const float* __restrict__ w, int n_in, int d, int C,
+                                                         T* __restrict__ out) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;   // (r_out, dir, dd)
+    if (i >= (int64_t)n_in * 2 * d) return;
+    const int dd = (int)(i % d), dir = (int)((i / d) & 1), r_out = (int)(i / (2 * d));
+    const int F = n_in / C, f = r_out / C, c = r_out - f * C;
+    const int r_in = c * F + f;
+    const float* src = w + (((int64_t)r_in * 2 + dir) * d + dd) * K;
+#pragma unroll
+    for (int kk = 0; kk < K; ++kk)
+        Elem<T>::st(out + (((int64_t)r_out * K + kk) * 2 + dir) * d + dd, src[kk]);
+}
+
+template <typename T, int K>
+__global__ __launch_bounds__(256) void sru_unpack_dw_kernel(const T* __restrict__ part, int S, int n_in, int d,
+                                                            int C, float* __restrict__ dw) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= (int64_t)n_in * 2 * d) return;
+    const int dd = (int)(i % d), dir = (int)((i / d) & 1), r_out = (int)(i / (2 * d));
+    const int F = n_in / C, f = r_out / C, c = r_out - f * C;
+    const int r_in = c * F + f;
+    const int64_t plane = (int64_t)n_in * K * 2 * d;
+    float acc[K];
+#pragma unroll
+    for (int kk = 0; kk < K; ++kk) acc[kk] = 0.f;
+    for (int s = 0; s < S; ++s) {
+#pragma unroll
+        for (int kk = 0; kk < K; ++kk)
+            acc[kk] += Elem<T>::ld(part + s * plane + (((int64_t)r_out * K + kk) * 2 + dir) * d + dd);
+    }
+    float* dst = dw + (((int64_t)r_in * 2 + dir) * d + dd) * K;
+#pragma unroll
+    for (int kk = 0; kk < K; ++kk) dst[kk] = acc[kk];
+}
+
+static int pack_check(const char* fn, int n_in, int d, int k, int C) {
+    SP_CHECK_ARG(n_in > 0 && d > 0 && (k == 3 || k == 4), "%s: bad shape n_in=%d d=%d k=%d", fn, n_in, d, k);
+    SP_CHECK_ARG(C >= 1 && n_in % C == 0, "%s: C=%d does not divide n_in=%d", fn, C, n_in);
+    return SP_OK;
+}
+}  // namespace sp
+
+extern "C" int sp_sru_pack_w(const float* weight, int n_in, int d, int k, int C, int dtype, void* out,
+                             void* stream) {
+    using namespace sp;
+    int rc = pack_check("sp_sru_pack_w", n_in, d, k, C);
+    if (rc) return rc;
+    SP_CHECK_ARG(weight && out, "sp_sru_pack_w: null pointer");
+    SP_CHECK_ARG(dtype == SP_F32 || dtype == SP_BF16, "sp_sru_pack_w: dtype %d", dtype);
+    hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+    const unsigned blocks = (unsigned)(((int64_t)n_in * 2 * d + 255) / 256);
+#define SP_PACK(T, K) hipLaunchKernelGGL((sru_pack_w_kernel<T, K>), dim3(blocks), dim3(256), 0, s, weight, n_in, d, C, (T*)out)
+    if (dtype == SP_F32) { if (k == 3) SP_PACK(float, 3); else SP_PACK(float, 4); }
+    else { if (k == 3) SP_PACK(__hip_bfloat16, 3); else SP_PACK(__hip_bfloat16, 4); }
+#undef SP_PACK
+    return check_launch("sru_pack_w_kernel");
+}
+
+extern "C" int sp_sru_unpack_dw(const void* partials, int S, int n_in, int d, int k, int C, int dtype,
+                                float* dweight, void* stream) {
+    using namespace sp;
+    int rc = pack_check("sp_sru_unpack_dw", n_in, d, k, C);
+    if (rc) return rc;
+    SP_CHECK_ARG(partials && dweight && S >= 1, "sp_sru_unpack_dw: null pointer or S=%d", S);
+    SP_CHECK_ARG(dtype == SP_F32 || dtype == SP_BF16, "sp_sru_unpack_dw: dtype %d", dtype);
+    hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+    const unsigned blocks = (unsigned)(((int64_t)n_in * 2 * d + 255) / 256);
+#define SP_UNPACK(T, K) hipLaunchKernelGGL((sru_unpack_dw_kernel<T, K>), dim3(blocks), dim3(256), 0, s, (const T*)partials, S, n_in, d, C, dweight)
+    if (dtype == SP_F32) { if (k == 3) SP_UNPACK(float, 3); else SP_UNPACK(float, 4); }
+    else { if (k == 3) SP_UNPACK(__hip_bfloat16, 3); else SP_UNPACK(__hip_bfloat16, 4); }
+#undef SP_UNPACK
+    return check_launch("sru_unpack_dw_kernel");
+}

@@ -109,8 +109,9 @@ class SRUCell(nn.Module):
         if self.training and self.dropout > 0:
             keep = 1.0 - self.dropout
             mask = torch.bernoulli(torch.full((B, 2 * d), keep, device=x.device)) / keep
-        return ops.sru_layer(x, self._ln_vec(ln.weight, torch.float32), self._ln_vec(ln.bias, torch.float32),
-                             self.kernel_weight(x.dtype), self.weight_c, self.bias, mask, d, ln.eps)
+        C = self.in_layout[0] if self.in_layout is not None else 1
+        return ops.sru_layer(x, ln.weight, ln.bias, self.weight, self.weight_c, self.bias, mask, d,
+                             self.num_matrices, C, ln.eps)
 
 
 class SRU(nn.Module):

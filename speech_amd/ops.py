@@ -314,43 +314,92 @@ def layer_norm(x, gamma, beta, eps=1e-5):
     return _LayerNormFn.apply(x, gamma, beta, eps)
 
 
+def sru_pack_w(weight, d, k, C, dtype):
+    """state_dict weight f32 [n_in, 2*d*k] (dir, d, k) -> Wk [n_in, k*2*d] in dtype, rows f*C + c."""
+    n_in = weight.shape[0]
+    out = torch.empty((n_in, k * 2 * d), dtype=dtype, device=weight.device)
+    with torch.cuda.device(weight.device):
+        check(lib().sp_sru_pack_w(ptr(weight), n_in, d, k, C, _lib.dtype_code(out), ptr(out), stream_ptr()),
+              "sp_sru_pack_w")
+    return out
+
+
+def sru_unpack_dw(partials, n_in, d, k, C):
+    """split-K partials [S, n_in, k*2*d] -> f32 dweight [n_in, 2*d*k] in the state_dict layout."""
+    S = partials.shape[0]
+    out = torch.empty((n_in, 2 * d * k), dtype=torch.float32, device=partials.device)
+    with torch.cuda.device(partials.device):
+        check(lib().sp_sru_unpack_dw(ptr(partials), S, n_in, d, k, C, _lib.dtype_code(partials), ptr(out),
+                                     stream_ptr()), "sp_sru_unpack_dw")
+    return out
+
+
+_bmm_f32_out = None
+
+
+def _splitk_dw(xn, gU2, S):
+    """dW partials [S, n_in, N] of xn^T gU: the library GEMM has only n_in/256 * N/256 = 48 output
+    tiles for 256 CUs at the reference's sizes, so K (= T*B) is split S ways as a batched GEMM;
+    partials in f32 when the library can write them."""
+    global _bmm_f32_out
+    M, n_in = xn.shape
+    a = xn.view(S, M // S, n_in).transpose(1, 2)
+    b = gU2.view(S, M // S, -1)
+    if xn.dtype == torch.float32:
+        return torch.bmm(a, b)
+    if _bmm_f32_out is None:
+        try:
+            torch.bmm(a[:, :8, :8], b[:, :8, :8], out_dtype=torch.float32)
+            _bmm_f32_out = True
+        except (TypeError, RuntimeError):
+            _bmm_f32_out = False
+    return torch.bmm(a, b, out_dtype=torch.float32) if _bmm_f32_out else torch.bmm(a, b)
+
+
 class _SRULayerFn(torch.autograd.Function):
-    """One SRU layer: LayerNorm (HIP) -> projection GEMM (library) -> recurrence (HIP), with a
-    hand-ordered backward: recurrence backward, the two GEMMs, LayerNorm backward fused with the
-    highway's residual gradient.  x [T,B,n_in]; ln_w/ln_b [n_in] (already in the input's feature
-    order); wk [n_in, k*2*d] in the kernels' (k, dir, channel) column order and x's dtype."""
+    """One SRU layer (net.py:61-72): LayerNorm (HIP) -> projection GEMM (library) -> recurrence (HIP),
+    with a hand-ordered backward: recurrence backward, the two GEMMs (dW split-K), LayerNorm backward
+    fused with the highway's residual gradient.  x [T,B,n_in] with feature order f*C + c; ln_w, ln_b,
+    weight are the state_dict parameters (f32, reference order); packing to the kernels' layout and the
+    inverse for the gradients are HIP kernels (sp_sru_pack_w / sp_sru_unpack_dw)."""
 
     @staticmethod
-    def forward(ctx, x, ln_w, ln_b, wk, wc, bias, mask, d, eps):
+    def forward(ctx, x, ln_w, ln_b, weight, wc, bias, mask, d, k, C, eps):
         T, B, n_in = x.shape
-        k = wk.shape[1] // (2 * d)
         x2 = x.contiguous().view(T * B, n_in)
-        g32, b32 = ln_w.detach().float().contiguous(), ln_b.detach().float().contiguous()
+        g32, b32 = ln_w.detach().float(), ln_b.detach().float()
+        if C > 1:
+            g32, b32 = g32.view(C, n_in // C).t().reshape(-1), b32.view(C, n_in // C).t().reshape(-1)
+        g32, b32 = g32.contiguous(), b32.contiguous()
         xn, mean, rstd = layernorm_fwd(x2, g32, b32, eps)
-        wk = wk.contiguous()
+        wk = sru_pack_w(weight.detach().float().contiguous(), d, k, C, x.dtype)
         U = torch.mm(xn, wk)
         wc32, bs32 = wc.detach().float().contiguous(), bias.detach().float().contiguous()
         xr = x2 if k == 3 else None
         h, c = sru_fwd(U, xr, wc32, bs32, mask, T, B, d, k)
         ctx.save_for_backward(x2, xn, mean, rstd, g32, wk, U, wc32, bs32, mask, c)
-        ctx.dims = (T, B, d, k, n_in)
-        ctx.pdt = (ln_w.dtype, ln_b.dtype, wc.dtype, bias.dtype)
+        ctx.dims = (T, B, d, k, n_in, C)
+        ctx.pdt = (ln_w.dtype, ln_b.dtype, weight.dtype, wc.dtype, bias.dtype)
         return h
 
     @staticmethod
     def backward(ctx, gh):
         x2, xn, mean, rstd, g32, wk, U, wc32, bs32, mask, c = ctx.saved_tensors
-        T, B, d, k, n_in = ctx.dims
+        T, B, d, k, n_in, C = ctx.dims
         gh = gh.contiguous().to(x2.dtype)
         gU, gxres, gwc, gbias = sru_bwd(U, x2 if k == 3 else None, wc32, bs32, mask, c, gh, T, B, d, k)
         gU2 = gU.view(T * B, -1)
-        gwk = torch.mm(xn.t(), gU2)
+        M = T * B
+        S = 4 if (M % 4 == 0 and M >= 4096) else 1
+        gw = sru_unpack_dw(_splitk_dw(xn, gU2, S), n_in, d, k, C)
         gxn = torch.mm(gU2, wk.t())
         gx, dg, db = layernorm_bwd(gxn, x2, mean, rstd, g32, gxres.view(T * B, n_in) if k == 3 else None)
+        if C > 1:
+            dg, db = dg.view(n_in // C, C).t().reshape(-1), db.view(n_in // C, C).t().reshape(-1)
         p = ctx.pdt
-        return (gx.view(T, B, n_in), dg.to(p[0]), db.to(p[1]), gwk, gwc.to(p[2]), gbias.to(p[3]),
-                None, None, None)
+        return (gx.view(T, B, n_in), dg.to(p[0]), db.to(p[1]), gw.to(p[2]), gwc.to(p[3]), gbias.to(p[4]),
+                None, None, None, None, None)
 
 
-def sru_layer(x, ln_w, ln_b, wk, wc, bias, mask, d, eps=1e-5):
-    return _SRULayerFn.apply(x, ln_w, ln_b, wk, wc, bias, mask, d, eps)
+def sru_layer(x, ln_w, ln_b, weight, wc, bias, mask, d, k, C=1, eps=1e-5):
+    return _SRULayerFn.apply(x, ln_w, ln_b, weight, wc, bias, mask, d, k, C, eps)

@@ -536,3 +536,22 @@ def test_layernorm_fwd_bwd(cuda, dtype, tol, shape):
         a, b_ = a.detach().cpu().double(), b_.detach()
         assert float((a - b_).abs().max()) <= tol * max(1.0, float(b_.abs().max())), what
     close(y, yr, "y"); close(xd.grad, xr.grad, "gx"); close(wd.grad, wr.grad, "dgamma"); close(bd.grad, br.grad, "dbeta")
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("n_in,d,k,C", [(128, 64, 3, 1), (160, 64, 4, 32), (1280, 512, 4, 32)])
+def test_sru_weight_pack_unpack(cuda, dtype, n_in, d, k, C):
+    """sp_sru_pack_w / sp_sru_unpack_dw against the index permutation written with torch views."""
+    from speech_amd import ops
+    g = torch.Generator().manual_seed(n_in + k)
+    w = torch.randn(n_in, 2 * d * k, generator=g)
+    ref = w.view(n_in, 2, d, k).permute(0, 3, 1, 2)                      # [n_in, k, 2, d]
+    ref = ref.reshape(C, n_in // C, k, 2, d).transpose(0, 1).reshape(n_in, k * 2 * d)   # rows f*C + c
+    out = ops.sru_pack_w(w.to(cuda), d, k, C, dtype)
+    assert torch.equal(out.cpu(), ref.to(dtype))
+    S = 3
+    parts = torch.randn(S, n_in, k * 2 * d, generator=g).to(dtype)
+    tot = parts.float().sum(0)
+    back = tot.view(n_in // C, C, k, 2, d).transpose(0, 1).reshape(n_in, k, 2, d).permute(0, 2, 3, 1)
+    got = ops.sru_unpack_dw(parts.to(cuda), n_in, d, k, C)
+    assert torch.allclose(got.cpu(), back.reshape(n_in, -1), rtol=1e-6, atol=1e-6)

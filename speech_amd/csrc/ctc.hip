@@ -1,32 +1,42 @@
 // Fused log-softmax + CTC loss + gradient for gfx950.
 // Replaces train.py:69-77 of the reference (F.log_softmax -> transpose -> torch.nn.CTCLoss).
 //
-// Three launches on one stream, all arithmetic in the log2 domain (v_exp_f32/v_log_f32 are
-// base-2 natively):
+// Three launches on one stream (v_exp_f32/v_log_f32 are base-2 natively, so log-probabilities
+// are kept in log2 units):
 //   K1 ctc_rows    (whole chip, one wave per (t,b) row): lse2 = log2 sum_c 2^(z_c*log2e) and the
 //                  compact per-frame row the lattice needs -- either the normalised row itself
 //                  (small vocabulary, V <= Lmax+1: indexed by class) or the gathered
 //                  (blank, l_1..l_L) log-probs (large vocabulary: indexed by label position).
 //   K2 ctc_lattice (2 workgroups per utterance: alpha forward in time, beta backward in time,
-//                  running concurrently).  Each thread owns NS consecutive lattice states in
-//                  registers; neighbours come from the adjacent lane by DPP wave shift, and only
-//                  the wave-boundary pair crosses LDS (one barrier per frame, none for a
-//                  single-wave lattice).  The per-frame rows are staged through LDS a chunk of
+//                  running concurrently).  The recursion is serial in time, so the kernel is
+//                  latency-bound and everything is done to keep the per-frame dependency chain
+//                  short: states are PROBABILITIES in f64 registers scaled by an exact power of two
+//                  (new = (a[s] + a[s-1] + skip*a[s-2]) * y: DPP move, add, fma, mul -- no exp/log
+//                  on the chain); the emission y = 2^(log2-prob) is built off the chain from an f32
+//                  v_exp_f32 of the fraction and an f64 ldexp of the integer part, so rows as
+//                  improbable as 2^-1000 stay exact; every 4th frame the wave maximum's exponent
+//                  (measured 3 frames earlier, off the chain) is folded into that ldexp and added
+//                  to the row's integer scale E_t.  Each thread owns NS consecutive lattice states;
+//                  neighbours come from the adjacent lane by DPP wave shift, and only the
+//                  wave-boundary state crosses LDS (one barrier per frame, none for a single-wave
+//                  lattice).  The per-frame rows are staged through LDS a chunk of
 //                  frames ahead (issue loads early, write to LDS late).  beta is the same
 //                  recursion on the reversed label sequence over reversed time, so there is one
 //                  code path.  Lattice rows are spilled to the workspace in coalesced rows.
 //   K3 ctc_grad    (whole chip, one wave per (t,b) row): posterior per state
 //                  2^(alpha+beta-lp+nll), summed per class in LDS, grad = (softmax - occ)*scale.
 //
-// Workspace: lse2[B*T] | rows[B][T][RW] (f32), then f64 alpha[B][T][SP] | beta_rev[B][T][SP] | nll2[B].
+// Workspace: lse2[B*T] | rows[B][T][RW] (f32), then f64 alpha[B][T][SP] | beta_rev[B][T][SP] | nll2[B];
+// SP = 2*Lmax+1 rounded up to 8 > S, and slot SP-1 of every lattice row holds that row's scale E
+// (true alpha_t(s) = alpha[b][t][s] * 2^E).
 //
-// Precision: alpha/beta reach thousands of log2 units, where one f32 ulp is ~2e-4 and a plain
-// f32 log-space recursion (torch's included) random-walks to ~3e-4 relative error in the
-// posteriors.  K2 keeps the lattice states in f64 registers (the adds; exp2/log2 of the small
-// terms stay f32) and spills the rows as f64: for tightly constrained alignments the states that
-// carry the posterior sit hundreds of units below the row maximum, so an f32 spill relative to
-// any per-row offset loses the same digits again.  K3 forms alpha + beta - lp - log-likelihood
-// in f64 and exponentiates in f32.
+// Precision: log alpha/beta reach thousands of log2 units, where one f32 ulp is ~2e-4: a plain f32
+// log-space recursion (torch's included) random-walks to ~3e-4 relative error in the posteriors.
+// Scaled f64 probabilities carry 53 bits through every add; the only f32 roundings are the
+// emission exp2 (1 ulp) and K1's log-sum-exp.  The lattice is spilled as f64: for tightly
+// constrained alignments the states that carry the posterior sit hundreds of binary orders below
+// the row maximum (f64 reaches 2^-1022 below it; anything smaller is a posterior of zero).  K3
+// multiplies alpha*beta in f64 and applies 2^(E_a + E_b - log2 y - log2 P) by ldexp.
 #include "common.h"
 
 namespace sp {
@@ -107,31 +117,40 @@ __global__ __launch_bounds__(256) void ctc_rows_kernel(
 // -------------------------------------------------------------------------------------------
 // K2: alpha / beta lattice
 // -------------------------------------------------------------------------------------------
-__device__ __forceinline__ int lane_shr1_i(int v, int fill) {
-    // lane i receives lane i-1's value; lane 0 receives `fill`
-    return __builtin_amdgcn_update_dpp(fill, v, 0x138 /*wave_shr:1*/, 0xF, 0xF, false);
+__device__ __forceinline__ int lane_shr1_i(int v) {
+    // lane i receives lane i-1's value; lane 0 receives 0
+    return __builtin_amdgcn_update_dpp(0, v, 0x138 /*wave_shr:1*/, 0xF, 0xF, false);
 }
-__device__ __forceinline__ double lane_shr1(double v) {
-    // -inf as f64 = 0xFFF00000'00000000
-    const int lo = lane_shr1_i(__double2loint(v), 0);
-    const int hi = lane_shr1_i(__double2hiint(v), (int)0xFFF00000);
-    return __hiloint2double(hi, lo);
+__device__ __forceinline__ double lane_shr1(double v) {  // lane 0 receives +0.0
+    return __hiloint2double(lane_shr1_i(__double2hiint(v)), lane_shr1_i(__double2loint(v)));
+}
+// wave-wide max of a non-negative int on the VALU only (DPP within each row of 16 lanes, then four
+// v_readlane): no LDS round trips, so it can sit beside the recursion without stalling it
+__device__ __forceinline__ int wave_max_i(int v) {
+    v = max(v, __builtin_amdgcn_update_dpp(0, v, 0xB1 /*quad_perm [1,0,3,2]*/, 0xF, 0xF, false));
+    v = max(v, __builtin_amdgcn_update_dpp(0, v, 0x4E /*quad_perm [2,3,0,1]*/, 0xF, 0xF, false));
+    v = max(v, __builtin_amdgcn_update_dpp(0, v, 0x141 /*row_half_mirror*/, 0xF, 0xF, false));
+    v = max(v, __builtin_amdgcn_update_dpp(0, v, 0x140 /*row_mirror*/, 0xF, 0xF, false));
+    return max(max(__builtin_amdgcn_readlane(v, 0), __builtin_amdgcn_readlane(v, 16)),
+               max(__builtin_amdgcn_readlane(v, 32), __builtin_amdgcn_readlane(v, 48)));
+}
+// 2^(x - shift) as f64 for x <= 0 (a log2-probability; -inf allowed) and integer shift: f32 exp2 of
+// the fraction (in [1,2), 1 ulp), exact f64 ldexp of the integer part.
+__device__ __forceinline__ double exp2_wide(float x, int shift) {
+    x = fmaxf(x, -1200.f);
+    const float n = floorf(x);
+    const double m = (double)__builtin_amdgcn_exp2f(x - n);
+    return ldexp(m, (int)n - shift);
+}
+// log2 of a non-negative f64 of any magnitude (0 -> -inf)
+__device__ __forceinline__ double log2_wide(double p) {
+    if (!(p > 0.0)) return p == 0.0 ? -(double)INFINITY : p;
+    int ex;
+    const double mant = frexp(p, &ex);
+    return (double)ex + (double)log2f((float)mant);
 }
 
-// log2(2^a + 2^b + 2^c): differences and the final add in f64 (alpha reaches thousands of log2
-// units; an f32 add there costs 2e-4 per step), exp2/log2 of the small terms in f32.
-__device__ __forceinline__ double lse2_3(double a, double b, double c) {
-    const double m = fmax(a, fmax(b, c));
-    const double m2 = (m == -(double)INFINITY) ? 0.0 : m;
-    const float s = exp2f((float)(a - m2)) + exp2f((float)(b - m2)) + exp2f((float)(c - m2));
-    return m2 + (double)log2f(s);
-}
-__device__ __forceinline__ double lse2_2(double a, double b) {
-    const double m = fmax(a, b);
-    const double m2 = (m == -(double)INFINITY) ? 0.0 : m;
-    const float s = exp2f((float)(a - m2)) + exp2f((float)(b - m2));
-    return m2 + (double)log2f(s);
-}
+constexpr int kRescale = 4;  // frames between rescales (a measured exponent is applied 3 frames later)
 
 template <int W, int NS>
 __global__ __launch_bounds__(64 * W) void ctc_lattice_kernel(
@@ -142,7 +161,9 @@ __global__ __launch_bounds__(64 * W) void ctc_lattice_kernel(
     constexpr int NT = 64 * W;
     // LDS: two row-chunk buffers of kPF*NT float4 each, then boundary slots, then final pair
     __shared__ __attribute__((aligned(16))) float4 s_chunk[2][kPF * NT];
-    __shared__ double s_bnd[2][W][2];  // per wave: last state, second-to-last
+    __shared__ double s_bnd[2][W];   // per wave: its last state (previous frame)
+    __shared__ int s_emax[2][W];
+    __shared__ int s_rep[NT];
     __shared__ double s_fin[2];
 
     const int b = blockIdx.x, dir = blockIdx.y;
@@ -163,24 +184,53 @@ __global__ __launch_bounds__(64 * W) void ctc_lattice_kernel(
     }
 
     // ---- per-state constants ----
+    // lab'[k]: the label sequence in this recursion's order (reversed for beta)
+    auto labp = [&](int k) { return min(max((int)lab[dir ? L - 1 - k : k], 0), V - 1); };
     int ridx[NS];
-    bool valid[NS], skip[NS];
+    int need[NS];    // frames still required after this one to reach the end from this position
+    double skm[NS];  // 1.0 where the s-2 transition exists
+    {
+        // thread tid owns label indices [tid*NS/2, tid*NS/2 + NS/2) (positions 2k and 2k+1)
+        constexpr int NK = NS / 2;
+        int rflag[NK], cnt = 0;
+#pragma unroll
+        for (int q = 0; q < NK; ++q) {
+            const int k = tid * NK + q;
+            rflag[q] = (k >= 1 && k < L && labp(k) == labp(k - 1)) ? 1 : 0;   // mandatory blank before k
+            cnt += rflag[q];
+        }
+        s_rep[tid] = cnt;
+        __syncthreads();
+        int after = 0;  // repeats among labels owned by higher threads
+        for (int u = tid + 1; u < NT; ++u) after += s_rep[u];
+#pragma unroll
+        for (int q = NK - 1; q >= 0; --q) {
+            const int k = tid * NK + q;
+            // R(k) = #repeat pairs (j-1, j) with j > k
+            const int Rk = after;
+            const int need_label = (L - 1 - k) + Rk;            // position 2k+1
+            need[2 * q + 1] = need_label;
+            need[2 * q] = (k < L) ? need_label + 1 : 0;          // blank before label k; final blank: 0
+            after += rflag[q];
+        }
+    }
 #pragma unroll
     for (int j = 0; j < NS; ++j) {
         const int sp_ = tid * NS + j;           // position in this recursion's order
         const int s = dir ? S - 1 - sp_ : sp_;   // real lattice state
-        valid[j] = sp_ < S;
         ridx[j] = 0;
-        skip[j] = false;
-        if (valid[j]) {
+        skm[j] = 0.0;
+        if (sp_ < S) {
             int cls = blank;
             if (s & 1) cls = min(max((int)lab[(s - 1) >> 1], 0), V - 1);
             ridx[j] = modeB ? cls : ((s & 1) ? (s + 1) >> 1 : 0);
             if ((s & 1) && sp_ >= 2) {
                 const int s2 = dir ? s + 2 : s - 2;  // the state two steps earlier in this order
                 const int cls2 = min(max((int)lab[(s2 - 1) >> 1], 0), V - 1);
-                skip[j] = cls != cls2;
+                skm[j] = cls != cls2 ? 1.0 : 0.0;
             }
+        } else {
+            need[j] = 0x3FFFFFFF;  // never live
         }
     }
 
@@ -209,60 +259,110 @@ __global__ __launch_bounds__(64 * W) void ctc_lattice_kernel(
     SP_CTC_COMMIT(0);
     __syncthreads();
 
-    const double kNegInf = -(double)INFINITY;
+    // a(-1) = delta(position 0): one step of the general recurrence then yields the CTC start
+    // condition (positions 0 and 1 take their emission, everything else 0)
     double a[NS];
 #pragma unroll
-    for (int j = 0; j < NS; ++j) a[j] = kNegInf;
+    for (int j = 0; j < NS; ++j) a[j] = (tid * NS + j == 0) ? 1.0 : 0.0;
+    int E = 0;  // alpha_true = a * 2^E
+    const bool spill_ok = tid * NS < SP;
+    const bool e_slot = (tid + 1) * NS == SP;   // this lane's last slot is row[SP-1]
+    if (W > 1) {
+        if (tid < W) s_bnd[0][tid] = 0.0;   // a(-1) of every wave's last position
+        __syncthreads();
+    }
 
     int i = 0;
     for (int c = 0; c < nchunks; ++c) {
         if (c + 1 < nchunks) SP_CTC_ISSUE(c + 1);
         const float* buf = reinterpret_cast<const float*>(s_chunk[c & 1]);
         const int lo = chunk_lo(c), hi = chunk_hi(c);
-        for (int k = 0; k < hi - lo; ++k, ++i) {
-            const int t = dir ? Tb - 1 - i : i;
-            const float* row = buf + (t - lo) * RW;
-            float lp[NS];
+        const int nsteps = hi - lo;
+        // blocks of kRescale frames: emissions of the whole block first (LDS reads, exp2, ldexp --
+        // all independent of the recursion), then the frames' dependency chains back to back
+        for (int k0 = 0; k0 < nsteps; k0 += kRescale) {
+            const int nb = min(kRescale, nsteps - k0);
+            // scale: exponent of the current maximum, folded into the block's last frame
+            int dp = 0;
+            if (nb == kRescale) {
+                double m = a[0];
 #pragma unroll
-            for (int j = 0; j < NS; ++j) lp[j] = row[ridx[j]];
-            if (i == 0) {
-#pragma unroll
-                for (int j = 0; j < NS; ++j) {
-                    const int sp_ = tid * NS + j;
-                    a[j] = (valid[j] && sp_ < 2) ? (double)lp[j] : kNegInf;
-                }
-            } else {
-                double p1 = lane_shr1(a[NS - 1]);
-                double p2 = lane_shr1(a[NS - 2]);
+                for (int j = 1; j < NS; ++j) m = fmax(m, a[j]);
+                const int e = wave_max_i((__double2hiint(m) >> 20) & 0x7FF);
                 if (W > 1) {
-                    if (lane == 0 && wave > 0) {
-                        p1 = s_bnd[i & 1][wave - 1][0];
-                        p2 = s_bnd[i & 1][wave - 1][1];
-                    }
+                    if (lane == 0) s_emax[(i / kRescale) & 1][wave] = e;   // read after >= 1 barrier
+                } else {
+                    dp = e ? e - 1023 : 0;
                 }
-                double n_[NS];
+            }
+            double y[kRescale][NS];
+#pragma unroll
+            for (int q = 0; q < kRescale; ++q) {
+                const int iq = i + min(q, nb - 1);
+                const int t = dir ? Tb - 1 - iq : iq;
+                const float* row = buf + (t - lo) * RW;
+                const int rem = Tb - 1 - iq;  // frames left: positions that need more are dead (exact
+                                              // pruning: a dead position only ever feeds dead positions)
 #pragma unroll
                 for (int j = 0; j < NS; ++j) {
-                    const double x1 = (j >= 1) ? a[j - 1] : p1;
-                    const double x2 = (j >= 2) ? a[j - 2] : (j == 1 ? p1 : p2);
-                    // j == 1: s'-2 is the previous lane's last state (p1); j == 0: its second-to-last
-                    const double x2s = skip[j] ? x2 : kNegInf;
-                    n_[j] = valid[j] ? lse2_3(a[j], x1, x2s) + (double)lp[j] : kNegInf;
+                    const float lp = row[ridx[j]];
+                    float x = fmaxf(lp, -1200.f);
+                    const float n = floorf(x);
+                    const double mnt = (double)__builtin_amdgcn_exp2f(x - n);
+                    // the block's scale shift is folded in below for q == kRescale-1 (W == 1) or
+                    // applied to y after the barrier-protected read (W > 1)
+                    const int sh = (W == 1 && q == kRescale - 1) ? dp : 0;
+                    const double v = ldexp(mnt, (int)n - sh);
+                    y[q][j] = need[j] <= rem ? v : 0.0;
                 }
-#pragma unroll
-                for (int j = 0; j < NS; ++j) a[j] = n_[j];
             }
-            // spill the lattice row (coalesced 16-byte stores)
-            double* orow = out + (int64_t)t * SP + tid * NS;
 #pragma unroll
-            for (int j = 0; j < NS; j += 2)
-                if (tid * NS + j < SP) *reinterpret_cast<double2*>(orow + j) = make_double2(a[j], a[j + 1]);
-            if (W > 1) {
-                if (lane == 63) {
-                    s_bnd[(i + 1) & 1][wave][0] = a[NS - 1];
-                    s_bnd[(i + 1) & 1][wave][1] = a[NS - 2];
+            for (int q = 0; q < kRescale; ++q) {
+                if (q < nb) {
+                    const int t = dir ? Tb - 1 - i : i;
+                    if (W > 1 && q == kRescale - 1) {
+                        int e = 0;
+#pragma unroll
+                        for (int w = 0; w < W; ++w) e = max(e, s_emax[(i / kRescale) & 1][w]);
+                        dp = e ? e - 1023 : 0;
+#pragma unroll
+                        for (int j = 0; j < NS; ++j) y[q][j] = ldexp(y[q][j], -dp);
+                    }
+                    double p1 = lane_shr1(a[NS - 1]);
+                    if (W > 1) {
+                        if (lane == 0 && wave > 0) p1 = s_bnd[i & 1][wave - 1];
+                    }
+                    double n_[NS];
+#pragma unroll
+                    for (int j = 0; j < NS; ++j) {
+                        // NS is even: position parity == state parity; s-1 and s-2 of an odd (label)
+                        // position j are a[j-1], a[j-2] (the previous lane's last state for j == 1)
+                        const double x1 = (j >= 1) ? a[j - 1] : p1;
+                        const double x2 = (j >= 2) ? a[j - 2] : p1;
+                        const double base = (j >= 1) ? a[j] + x1 : a[j];   // j >= 1: off the DPP chain
+                        n_[j] = (j >= 1) ? fma(skm[j], x2, base) * y[q][j] : (base + x1) * y[q][j];
+                    }
+#pragma unroll
+                    for (int j = 0; j < NS; ++j) a[j] = n_[j];
+                    if (q == kRescale - 1) E += dp;
+                    // spill the lattice row (coalesced 16-byte stores) and its scale
+                    // (one vector-memory op per lane and frame: the 64-deep vmem queue of the wave
+                    // is what the write latency is divided by).  Slot SP-1 >= S is never a state: it
+                    // carries the row's scale E.
+                    if (spill_ok) {
+                        double* orow = out + (int64_t)t * SP + tid * NS;
+#pragma unroll
+                        for (int j = 0; j < NS; j += 2) {
+                            const double hi_ = (e_slot && j == NS - 2) ? (double)E : a[j + 1];
+                            *reinterpret_cast<double2*>(orow + j) = make_double2(a[j], hi_);
+                        }
+                    }
+                    if (W > 1) {
+                        if (lane == 63) s_bnd[(i + 1) & 1][wave] = a[NS - 1];
+                        __syncthreads();
+                    }
+                    ++i;
                 }
-                __syncthreads();
             }
         }
         if (c + 1 < nchunks) SP_CTC_COMMIT(c + 1);
@@ -278,7 +378,209 @@ __global__ __launch_bounds__(64 * W) void ctc_lattice_kernel(
         }
         __syncthreads();
         if (tid == 0) {
-            const double ll2 = (S > 1) ? lse2_2(s_fin[0], s_fin[1]) : s_fin[0];  // log2 likelihood
+            const double p = (S > 1) ? s_fin[0] + s_fin[1] : s_fin[0];
+            const double ll2 = log2_wide(p) + (double)E;  // log2 likelihood
+            nll2[b] = -ll2;
+            nll[b] = (float)(-ll2 * 0.69314718055994530942);
+        }
+    }
+}
+
+// -------------------------------------------------------------------------------------------
+// K2, single-wave lattices (S <= 256: every sentencepiece-sized transcript): the recursion wave is
+// issue-bound once the chain is short, so the emission work moves to two HELPER waves of the same
+// workgroup.  Helpers turn the compact log2-prob rows of a chunk of frames into pruned f64
+// emissions y[frame][position] in LDS (double-buffered, one barrier per chunk); the recursion wave
+// only reads them back (ds_read_b128), shifts, adds, multiplies and spills.
+// -------------------------------------------------------------------------------------------
+template <int NS>
+__global__ __launch_bounds__(192) void ctc_lattice1_kernel(
+    const float* __restrict__ rows, const int64_t* __restrict__ labels, int label_stride,
+    const int32_t* __restrict__ in_len, const int32_t* __restrict__ lab_len, int T, int V,
+    int blank, int Lmax, int RW, int SP, int modeB, double* __restrict__ alpha,
+    double* __restrict__ beta_rev, double* __restrict__ nll2, float* __restrict__ nll) {
+    constexpr int TB = 64 / NS;   // frames per chunk
+    constexpr int PW = 64 * NS;   // positions per frame
+    constexpr int NK = NS / 2;    // labels per lane
+    constexpr int HF = TB / 2;    // frames per helper wave and chunk
+    __shared__ __attribute__((aligned(16))) double s_y[2][TB][PW];   // 64 KB
+    __shared__ int s_rep[64];
+    __shared__ double s_fin[2];
+
+    const int b = blockIdx.x, dir = blockIdx.y;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int Tb = min(max(in_len[b], 0), T);
+    const int L = min(max(lab_len[b], 0), Lmax);
+    const int S = 2 * L + 1;
+    const int64_t* lab = labels + (int64_t)b * label_stride;
+    const float* rows_b = rows + (int64_t)b * T * RW;
+
+    if (Tb == 0) {
+        if (dir == 0 && tid == 0) {
+            nll[b] = (L == 0) ? 0.f : INFINITY;
+            nll2[b] = (L == 0) ? 0.0 : (double)INFINITY;
+        }
+        return;
+    }
+
+    // ---- per-position constants of the positions lane*NS .. lane*NS+NS-1 (every wave computes them) ----
+    auto labp = [&](int k) { return min(max((int)lab[dir ? L - 1 - k : k], 0), V - 1); };
+    int need[NS];    // frames still required after this one to reach the end from this position
+    int rlab[NK];    // row index of the lane's labels
+    double skm[NK];  // 1.0 where the s-2 transition into the label position exists
+    {
+        int rflag[NK], cnt = 0;
+#pragma unroll
+        for (int q = 0; q < NK; ++q) {
+            const int k = lane * NK + q;
+            rflag[q] = (k >= 1 && k < L && labp(k) == labp(k - 1)) ? 1 : 0;   // mandatory blank before k
+            cnt += rflag[q];
+            rlab[q] = 0;
+            skm[q] = 0.0;
+            if (k < L) {
+                // real label index of recursion-order label k is (dir ? L-1-k : k); rows are indexed by
+                // class (modeB) or by real label position + 1
+                rlab[q] = modeB ? labp(k) : (dir ? L - k : k + 1);
+                skm[q] = (k >= 1 && !rflag[q]) ? 1.0 : 0.0;
+            }
+        }
+        if (wave == 0) s_rep[lane] = cnt;
+        __syncthreads();
+        int after = 0;  // repeats among labels owned by higher lanes
+        for (int u = lane + 1; u < 64; ++u) after += s_rep[u];
+#pragma unroll
+        for (int q = NK - 1; q >= 0; --q) {
+            const int k = lane * NK + q;
+            const int need_label = (L - 1 - k) + after;           // position 2k+1
+            need[2 * q + 1] = (k < L) ? need_label : 0x3FFFFFFF;
+            need[2 * q] = (k < L) ? need_label + 1 : (k == L ? 0 : 0x3FFFFFFF);   // final blank: 0
+            after += rflag[q];
+        }
+    }
+    const int rblank = modeB ? blank : 0;
+    const int nchunks = (Tb + TB - 1) / TB;
+
+    if (wave > 0) {
+        // ------------------------------------------------------------------ helpers
+        const int hw = wave - 1;
+        for (int c = 0; c < nchunks; ++c) {
+            float lpb[HF], lpl[HF][NK];
+#pragma unroll
+            for (int f = 0; f < HF; ++f) {
+                const int i = min(c * TB + 2 * f + hw, Tb - 1);
+                const int t = dir ? Tb - 1 - i : i;
+                const float* row = rows_b + (int64_t)t * RW;
+                lpb[f] = row[rblank];
+#pragma unroll
+                for (int q = 0; q < NK; ++q) lpl[f][q] = row[rlab[q]];
+            }
+#pragma unroll
+            for (int f = 0; f < HF; ++f) {
+                const int i = c * TB + 2 * f + hw;
+                const int rem = Tb - 1 - i;  // frames left: positions that need more are dead (exact
+                                             // pruning: a dead position only ever feeds dead positions)
+                const float xb = fmaxf(lpb[f], -1200.f);
+                const float nb_ = floorf(xb);
+                const double yb = ldexp((double)__builtin_amdgcn_exp2f(xb - nb_), (int)nb_);
+                double yv[NS];
+#pragma unroll
+                for (int q = 0; q < NK; ++q) {
+                    const float xl = fmaxf(lpl[f][q], -1200.f);
+                    const float nl = floorf(xl);
+                    const double yl = ldexp((double)__builtin_amdgcn_exp2f(xl - nl), (int)nl);
+                    yv[2 * q] = need[2 * q] <= rem ? yb : 0.0;
+                    yv[2 * q + 1] = need[2 * q + 1] <= rem ? yl : 0.0;
+                }
+                double* dst = &s_y[c & 1][2 * f + hw][lane * NS];
+#pragma unroll
+                for (int j = 0; j < NS; j += 2)
+                    *reinterpret_cast<double2*>(dst + j) = make_double2(yv[j], yv[j + 1]);
+            }
+            __syncthreads();  // chunk c is ready; the recursion wave released buffer (c+1)&1 at this barrier
+        }
+        return;
+    }
+
+    // ---------------------------------------------------------------------- recursion wave
+    double* out = (dir ? beta_rev : alpha) + (int64_t)b * T * SP;
+    // a(-1) = delta(position 0): one step of the general recurrence then yields the CTC start
+    // condition (positions 0 and 1 take their emission, everything else 0)
+    double a[NS];
+#pragma unroll
+    for (int j = 0; j < NS; ++j) a[j] = (lane * NS + j == 0) ? 1.0 : 0.0;
+    int E = 0;  // alpha_true = a * 2^E
+    const bool spill_ok = lane * NS < SP;
+    const bool e_slot = (lane + 1) * NS == SP;   // this lane's last slot is row[SP-1]: carries E
+    int i = 0;
+    for (int c = 0; c < nchunks; ++c) {
+        __syncthreads();
+        const int nsteps = min(TB, Tb - c * TB);
+        for (int k0 = 0; k0 < nsteps; k0 += kRescale) {
+            const int nb = min(kRescale, nsteps - k0);
+            int dp = 0;
+            if (nb == kRescale) {   // exponent of the current maximum, folded into the block's last frame
+                double m = a[0];
+#pragma unroll
+                for (int j = 1; j < NS; ++j) m = fmax(m, a[j]);
+                const int e = wave_max_i((__double2hiint(m) >> 20) & 0x7FF);
+                dp = e ? e - 1023 : 0;
+            }
+            double y[kRescale][NS];
+#pragma unroll
+            for (int q = 0; q < kRescale; ++q) {
+                const double* src = &s_y[c & 1][k0 + q][lane * NS];   // k0 + q < TB: rows past the end hold junk
+#pragma unroll
+                for (int j = 0; j < NS; j += 2) {
+                    const double2 v = *reinterpret_cast<const double2*>(src + j);
+                    y[q][j] = v.x;
+                    y[q][j + 1] = v.y;
+                }
+            }
+#pragma unroll
+            for (int j = 0; j < NS; ++j) y[kRescale - 1][j] = ldexp(y[kRescale - 1][j], -dp);
+#pragma unroll
+            for (int q = 0; q < kRescale; ++q) {
+                if (q < nb) {
+                    const int t = dir ? Tb - 1 - i : i;
+                    const double p1 = lane_shr1(a[NS - 1]);
+                    double n_[NS];
+#pragma unroll
+                    for (int j = 0; j < NS; ++j) {
+                        // position parity == state parity; s-1 and s-2 of an odd (label) position j are
+                        // a[j-1], a[j-2] (the previous lane's last state for j == 1)
+                        const double x1 = (j >= 1) ? a[j - 1] : p1;
+                        const double x2 = (j >= 2) ? a[j - 2] : p1;
+                        const double base = (j >= 1) ? a[j] + x1 : a[j];   // j >= 1: off the DPP chain
+                        n_[j] = (j & 1) ? fma(skm[j >> 1], x2, base) * y[q][j] : (a[j] + x1) * y[q][j];
+                    }
+#pragma unroll
+                    for (int j = 0; j < NS; ++j) a[j] = n_[j];
+                    if (q == kRescale - 1) E += dp;
+                    if (spill_ok) {
+                        double* orow = out + (int64_t)t * SP + lane * NS;
+#pragma unroll
+                        for (int j = 0; j < NS; j += 2) {
+                            const double hi_ = (e_slot && j == NS - 2) ? (double)E : a[j + 1];
+                            *reinterpret_cast<double2*>(orow + j) = make_double2(a[j], hi_);
+                        }
+                    }
+                    ++i;
+                }
+            }
+        }
+    }
+    if (dir == 0) {
+#pragma unroll
+        for (int j = 0; j < NS; ++j) {
+            const int sp_ = lane * NS + j;
+            if (sp_ == S - 1) s_fin[0] = a[j];
+            if (sp_ == S - 2) s_fin[1] = a[j];
+        }
+        __builtin_amdgcn_wave_barrier();
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        if (lane == 0) {
+            const double p = (S > 1) ? s_fin[0] + s_fin[1] : s_fin[0];
+            const double ll2 = log2_wide(p) + (double)E;  // log2 likelihood
             nll2[b] = -ll2;
             nll[b] = (float)(-ll2 * 0.69314718055994530942);
         }
@@ -320,10 +622,11 @@ __global__ __launch_bounds__(256) void ctc_grad_kernel(
         }
         const int L = min(max(lab_len[b], 0), Lmax);
         const int S = 2 * L + 1;
-        const double nll2 = nll2d[b];
         const float scale = grad_scale / ((float)B * (float)max(L, 1));
         const double* arow = alpha + ((int64_t)b * T + t) * SP;
         const double* brow = beta_rev + ((int64_t)b * T + t) * SP;
+        // 2^gexp * alpha_hat * beta_hat / y = the state posterior; slot SP-1 of a row is its scale E
+        const double gexp = nll2d[b] + arow[SP - 1] + brow[SP - 1];
         const float* lrow = rows + ((int64_t)b * T + t) * RW;
         const int64_t* lab = labels + (int64_t)b * label_stride;
 
@@ -333,7 +636,15 @@ __global__ __launch_bounds__(256) void ctc_grad_kernel(
             int cls = blank;
             if (s & 1) cls = min(max((int)lab[(s - 1) >> 1], 0), V - 1);
             const int ri = modeB ? cls : ((s & 1) ? (s + 1) >> 1 : 0);
-            const float gam = exp2f((float)(arow[s] + brow[S - 1 - s] - (double)lrow[ri] + nll2));
+            // alpha_hat and beta_hat can each sit ~1000 binary orders below their row maxima where the
+            // posterior peaks: multiply mantissas, add exponents, one ldexp
+            const double g = gexp - (double)lrow[ri];
+            const double gn = floor(g);
+            int xa, xb;
+            const double ma = frexp(arow[s], &xa), mb = frexp(brow[S - 1 - s], &xb);
+            const double pr = ma * mb * (double)__builtin_amdgcn_exp2f((float)(g - gn));
+            const double ge = fmax(fmin(gn + (double)(xa + xb), 4000.0), -4000.0);
+            const float gam = (float)ldexp(pr, (int)ge);
             if (s & 1) atomicAdd(&occ[cls], gam);
             else blank_acc += gam;
         }
@@ -355,9 +666,10 @@ static void launch_lattice(const CtcDims& d, float* ws, const int64_t* labels, i
                            const int32_t* in_len, const int32_t* lab_len, int blank, float* nll,
                            hipStream_t s) {
     double* dbl = reinterpret_cast<double*>(ws + d.off_dbl);
-    int TB = (kPF * 64 * W * 4) / d.RW;
+    int TB = (kPF * 64 * W * 4) / d.RW;   // RW <= 1024 and RW <= 128 W (see ctc_dims): TB >= 8
     if (TB > 64) TB = 64;
-    if (TB < 1) TB = 1;
+    TB &= ~(kRescale - 1);
+    if (TB < kRescale) TB = kRescale;
     hipLaunchKernelGGL((ctc_lattice_kernel<W, NS>), dim3(d.B, 2), dim3(64 * W), 0, s,
                        ws + d.off_rows, labels, label_stride, in_len, lab_len, d.T, d.V, blank,
                        d.Lmax, d.RW, d.SP, d.modeB, TB, dbl, dbl + (size_t)d.B * d.T * d.SP,
@@ -407,8 +719,15 @@ extern "C" int sp_ctc_fwd_bwd(const float* logits, int64_t stride_t, int64_t str
     }
     const int S = 2 * max_label_len + 1;
     // (waves, states per thread): smallest lattice that holds S states
-    if (S <= 128) launch_lattice<1, 2>(d, ws, labels, label_stride, input_lengths, label_lengths, blank, nll, s);
-    else if (S <= 256) launch_lattice<1, 4>(d, ws, labels, label_stride, input_lengths, label_lengths, blank, nll, s);
+    double* dblw = reinterpret_cast<double*>(ws + d.off_dbl);
+    if (S <= 128)
+        hipLaunchKernelGGL((ctc_lattice1_kernel<2>), dim3(B, 2), dim3(192), 0, s, ws + d.off_rows, labels, label_stride,
+                           input_lengths, label_lengths, T, V, blank, max_label_len, d.RW, d.SP, d.modeB, dblw,
+                           dblw + (size_t)B * T * d.SP, dblw + (size_t)2 * B * T * d.SP, nll);
+    else if (S <= 256)
+        hipLaunchKernelGGL((ctc_lattice1_kernel<4>), dim3(B, 2), dim3(192), 0, s, ws + d.off_rows, labels, label_stride,
+                           input_lengths, label_lengths, T, V, blank, max_label_len, d.RW, d.SP, d.modeB, dblw,
+                           dblw + (size_t)B * T * d.SP, dblw + (size_t)2 * B * T * d.SP, nll);
     else if (S <= 512) launch_lattice<2, 4>(d, ws, labels, label_stride, input_lengths, label_lengths, blank, nll, s);
     else if (S <= 1024) launch_lattice<4, 4>(d, ws, labels, label_stride, input_lengths, label_lengths, blank, nll, s);
     else launch_lattice<4, 8>(d, ws, labels, label_stride, input_lengths, label_lengths, blank, nll, s);

@@ -26,9 +26,10 @@
 //   K3 ctc_grad    (whole chip, one wave per (t,b) row): posterior per state
 //                  2^(alpha+beta-lp+nll), summed per class in LDS, grad = (softmax - occ)*scale.
 //
-// Workspace: lse2[B*T] | rows[B][T][RW] (f32), then f64 alpha[B][T][SP] | beta_rev[B][T][SP] | nll2[B];
-// SP = 2*Lmax+1 rounded up to 8 > S, and slot SP-1 of every lattice row holds that row's scale E
-// (true alpha_t(s) = alpha[b][t][s] * 2^E).
+// Workspace: lse2[B*T] | rows[B][T][RW] (f32), then f64 alpha[B][T][SP] | beta_rev[B][T][SP] | nll2[B]
+// | aux.  True alpha_t(s) = alpha[b][t][s] * 2^E_t.  SP = 2*Lmax+1 rounded up to 8 > S: the multi-wave
+// kernel keeps E_t in slot SP-1 of the row; the single-wave kernel writes E once per 4-frame block
+// into its aux block (and parks the stores of lanes beyond SP on a dummy row there).
 //
 // Precision: log alpha/beta reach thousands of log2 units, where one f32 ulp is ~2e-4: a plain f32
 // log-space recursion (torch's included) random-walks to ~3e-4 relative error in the posteriors.
@@ -45,6 +46,7 @@ constexpr float kLog2e = 1.4426950408889634f;
 constexpr int kMaxV = 4000;  // K3 keeps 4 x V floats of per-class sums in LDS (<= 64 KB)
 constexpr int kMaxL = 1023;
 constexpr int kPF = 8;  // float4 prefetch registers per thread in K2
+constexpr int kRescale = 4;  // K2: frames per rescale block (the exponent measured at its start is applied in its last frame)
 
 struct CtcDims {
     int T, B, V, Lmax;
@@ -53,6 +55,7 @@ struct CtcDims {
     int modeB; // 1: rows indexed by class, 0: by label position
     size_t off_lse, off_rows, total_floats;  // float offsets
     size_t off_dbl;  // float offset of the f64 block: alpha[B][T][SP] | beta_rev[B][T][SP] | nll2[B]
+    size_t off_aux;  // float offset of the aux f64 block (see ctc_dims)
     size_t total_bytes;
 };
 
@@ -68,6 +71,8 @@ static CtcDims ctc_dims(int T, int B, int V, int Lmax) {
     o = align_up(o, 4);
     d.off_dbl = o;
     o += 2 * ((size_t)2 * B * T * d.SP + B);  // doubles, counted in floats
+    d.off_aux = o;                            // single-wave lattice kernel: per (dir, b) a dummy spill
+    o += 2 * ((size_t)2 * B * (256 + T / kRescale + 2));   // row (256 doubles) and the scale E after each block
     d.total_floats = o;
     d.total_bytes = o * sizeof(float);
     return d;
@@ -114,12 +119,72 @@ __global__ __launch_bounds__(256) void ctc_rows_kernel(
     }
 }
 
+// K1, vector path (V % 4 == 0, 16-byte aligned rows, V <= 1024 * NV / 4): the row is read ONCE with
+// float4 loads and stays in registers for the max, the sum and (mode B) the normalised row.
+template <int NV>
+__global__ __launch_bounds__(256) void ctc_rows_vec_kernel(
+    const float* __restrict__ logits, int64_t st, int64_t sb, const int64_t* __restrict__ labels,
+    int label_stride, const int32_t* __restrict__ in_len, const int32_t* __restrict__ lab_len,
+    int T, int B, int V, int blank, int Lmax, int RW, int modeB, float* __restrict__ lse2,
+    float* __restrict__ rows) {
+    const int lane = threadIdx.x & 63;
+    const int wpb = blockDim.x >> 6;
+    const int V4 = V >> 2;
+    const int64_t nrows = (int64_t)T * B;
+    for (int64_t r = (int64_t)blockIdx.x * wpb + (threadIdx.x >> 6); r < nrows;
+         r += (int64_t)gridDim.x * wpb) {
+        const int b = (int)(r / T), t = (int)(r % T);
+        const int Tb = min(max(in_len[b], 0), T);
+        if (t >= Tb) continue;
+        const float* z = logits + t * st + b * sb;
+        const float4* z4 = reinterpret_cast<const float4*>(z);
+        float4 v[NV];
+#pragma unroll
+        for (int i = 0; i < NV; ++i) {
+            const int q = lane + 64 * i;
+            v[i] = q < V4 ? z4[q] : make_float4(-INFINITY, -INFINITY, -INFINITY, -INFINITY);
+        }
+        float m = -INFINITY;
+#pragma unroll
+        for (int i = 0; i < NV; ++i) m = fmaxf(m, fmaxf(fmaxf(v[i].x, v[i].y), fmaxf(v[i].z, v[i].w)));
+        m = wave_max(m);
+        const float mk = m * kLog2e;
+        float sum = 0.f;
+#pragma unroll
+        for (int i = 0; i < NV; ++i)
+            sum += exp2f(fmaf(v[i].x, kLog2e, -mk)) + exp2f(fmaf(v[i].y, kLog2e, -mk)) +
+                   exp2f(fmaf(v[i].z, kLog2e, -mk)) + exp2f(fmaf(v[i].w, kLog2e, -mk));
+        sum = wave_sum(sum);
+        const float l2 = mk + log2f(sum);
+        if (lane == 0) lse2[(int64_t)b * T + t] = l2;
+        float* out = rows + ((int64_t)b * T + t) * RW;
+        if (modeB) {
+            float4* out4 = reinterpret_cast<float4*>(out);   // RW == V here (V % 4 == 0)
+#pragma unroll
+            for (int i = 0; i < NV; ++i) {
+                const int q = lane + 64 * i;
+                if (q < V4)
+                    out4[q] = make_float4(fmaf(v[i].x, kLog2e, -l2), fmaf(v[i].y, kLog2e, -l2),
+                                          fmaf(v[i].z, kLog2e, -l2), fmaf(v[i].w, kLog2e, -l2));
+            }
+        } else {
+            const int L = min(max(lab_len[b], 0), Lmax);
+            for (int i = lane; i <= L; i += 64) {
+                int idx = blank;
+                if (i > 0) idx = (int)labels[(int64_t)b * label_stride + i - 1];
+                idx = min(max(idx, 0), V - 1);
+                out[i] = fmaf(z[idx], kLog2e, -l2);   // L1/L2 hit: the row was just read
+            }
+        }
+    }
+}
+
 // -------------------------------------------------------------------------------------------
 // K2: alpha / beta lattice
 // -------------------------------------------------------------------------------------------
 __device__ __forceinline__ int lane_shr1_i(int v) {
-    // lane i receives lane i-1's value; lane 0 receives 0
-    return __builtin_amdgcn_update_dpp(0, v, 0x138 /*wave_shr:1*/, 0xF, 0xF, false);
+    // lane i receives lane i-1's value; lane 0 receives 0 (bound_ctrl: no source lane -> 0)
+    return __builtin_amdgcn_update_dpp(0, v, 0x138 /*wave_shr:1*/, 0xF, 0xF, true);
 }
 __device__ __forceinline__ double lane_shr1(double v) {  // lane 0 receives +0.0
     return __hiloint2double(lane_shr1_i(__double2hiint(v)), lane_shr1_i(__double2loint(v)));
@@ -150,7 +215,6 @@ __device__ __forceinline__ double log2_wide(double p) {
     return (double)ex + (double)log2f((float)mant);
 }
 
-constexpr int kRescale = 4;  // frames between rescales (a measured exponent is applied 3 frames later)
 
 template <int W, int NS>
 __global__ __launch_bounds__(64 * W) void ctc_lattice_kernel(
@@ -398,7 +462,8 @@ __global__ __launch_bounds__(192) void ctc_lattice1_kernel(
     const float* __restrict__ rows, const int64_t* __restrict__ labels, int label_stride,
     const int32_t* __restrict__ in_len, const int32_t* __restrict__ lab_len, int T, int V,
     int blank, int Lmax, int RW, int SP, int modeB, double* __restrict__ alpha,
-    double* __restrict__ beta_rev, double* __restrict__ nll2, float* __restrict__ nll) {
+    double* __restrict__ beta_rev, double* __restrict__ aux, double* __restrict__ nll2,
+    float* __restrict__ nll) {
     constexpr int TB = 64 / NS;   // frames per chunk
     constexpr int PW = 64 * NS;   // positions per frame
     constexpr int NK = NS / 2;    // labels per lane
@@ -463,17 +528,22 @@ __global__ __launch_bounds__(192) void ctc_lattice1_kernel(
     if (wave > 0) {
         // ------------------------------------------------------------------ helpers
         const int hw = wave - 1;
-        for (int c = 0; c < nchunks; ++c) {
-            float lpb[HF], lpl[HF][NK];
+        // rows of chunk c+1 are requested before chunk c is converted: a helper never waits on HBM
+        float lpb[HF], lpl[HF][NK], nxb[HF], nxl[HF][NK];
+        auto fetch = [&](int c, float (&pb)[HF], float (&pl)[HF][NK]) {
 #pragma unroll
             for (int f = 0; f < HF; ++f) {
                 const int i = min(c * TB + 2 * f + hw, Tb - 1);
                 const int t = dir ? Tb - 1 - i : i;
                 const float* row = rows_b + (int64_t)t * RW;
-                lpb[f] = row[rblank];
+                pb[f] = row[rblank];
 #pragma unroll
-                for (int q = 0; q < NK; ++q) lpl[f][q] = row[rlab[q]];
+                for (int q = 0; q < NK; ++q) pl[f][q] = row[rlab[q]];
             }
+        };
+        fetch(0, lpb, lpl);
+        for (int c = 0; c < nchunks; ++c) {
+            fetch(min(c + 1, nchunks - 1), nxb, nxl);
 #pragma unroll
             for (int f = 0; f < HF; ++f) {
                 const int i = c * TB + 2 * f + hw;
@@ -496,6 +566,12 @@ __global__ __launch_bounds__(192) void ctc_lattice1_kernel(
                 for (int j = 0; j < NS; j += 2)
                     *reinterpret_cast<double2*>(dst + j) = make_double2(yv[j], yv[j + 1]);
             }
+#pragma unroll
+            for (int f = 0; f < HF; ++f) {
+                lpb[f] = nxb[f];
+#pragma unroll
+                for (int q = 0; q < NK; ++q) lpl[f][q] = nxl[f][q];
+            }
             __syncthreads();  // chunk c is ready; the recursion wave released buffer (c+1)&1 at this barrier
         }
         return;
@@ -508,27 +584,54 @@ __global__ __launch_bounds__(192) void ctc_lattice1_kernel(
     double a[NS];
 #pragma unroll
     for (int j = 0; j < NS; ++j) a[j] = (lane * NS + j == 0) ? 1.0 : 0.0;
-    int E = 0;  // alpha_true = a * 2^E
+    int E = 0;         // alpha_true = a * 2^E
+    // Everything in the frame loop is straight-line: an exec-mask branch costs the serial wave ~30
+    // cycles per frame.  Lanes beyond the padded row keep storing into a dummy row (step 0), and the
+    // scale is not stored per row but once per rescale block (all lanes write the same value):
+    // aux block of this (dir, b) = dummy[256] | Ecum[T/kRescale + 2].
+    const int aux_stride = 256 + T / kRescale + 2;
+    double* aux_b = aux + ((int64_t)dir * gridDim.x + b) * aux_stride;
+    double* ecum = aux_b + 256;
     const bool spill_ok = lane * NS < SP;
-    const bool e_slot = (lane + 1) * NS == SP;   // this lane's last slot is row[SP-1]: carries E
+    // row pointer of the frame being written: walks forward (alpha) or backward (beta) by one row
+    double* orow = spill_ok ? out + (int64_t)(dir ? Tb - 1 : 0) * SP + lane * NS : aux_b + lane * NS;
+    const int64_t ostep = spill_ok ? (dir ? -(int64_t)SP : (int64_t)SP) : 0;
+    auto step = [&](const double (&yq)[NS]) {
+        const double p1 = lane_shr1(a[NS - 1]);
+        double n_[NS];
+#pragma unroll
+        for (int j = 0; j < NS; ++j) {
+            // position parity == state parity; s-1 and s-2 of an odd (label) position j are
+            // a[j-1], a[j-2] (the previous lane's last state for j == 1)
+            const double x1 = (j >= 1) ? a[j - 1] : p1;
+            const double x2 = (j >= 2) ? a[j - 2] : p1;
+            const double base = (j >= 1) ? a[j] + x1 : a[j];   // j >= 1: off the DPP chain
+            n_[j] = (j & 1) ? fma(skm[j >> 1], x2, base) * yq[j] : (a[j] + x1) * yq[j];
+        }
+#pragma unroll
+        for (int j = 0; j < NS; ++j) a[j] = n_[j];
+    };
+    auto spill = [&]() {   // one vector-memory op per lane and frame (NS == 2)
+#pragma unroll
+        for (int j = 0; j < NS; j += 2) *reinterpret_cast<double2*>(orow + j) = make_double2(a[j], a[j + 1]);
+        orow += ostep;
+    };
     int i = 0;
     for (int c = 0; c < nchunks; ++c) {
         __syncthreads();
         const int nsteps = min(TB, Tb - c * TB);
-        for (int k0 = 0; k0 < nsteps; k0 += kRescale) {
-            const int nb = min(kRescale, nsteps - k0);
-            int dp = 0;
-            if (nb == kRescale) {   // exponent of the current maximum, folded into the block's last frame
-                double m = a[0];
+        int k0 = 0;
+        for (; k0 + kRescale <= nsteps; k0 += kRescale) {   // full blocks: straight-line code
+            // exponent of the current maximum, folded into the block's last frame
+            double m = a[0];
 #pragma unroll
-                for (int j = 1; j < NS; ++j) m = fmax(m, a[j]);
-                const int e = wave_max_i((__double2hiint(m) >> 20) & 0x7FF);
-                dp = e ? e - 1023 : 0;
-            }
+            for (int j = 1; j < NS; ++j) m = fmax(m, a[j]);
+            const int e = wave_max_i((__double2hiint(m) >> 20) & 0x7FF);
+            const int dp = e ? e - 1023 : 0;
             double y[kRescale][NS];
 #pragma unroll
             for (int q = 0; q < kRescale; ++q) {
-                const double* src = &s_y[c & 1][k0 + q][lane * NS];   // k0 + q < TB: rows past the end hold junk
+                const double* src = &s_y[c & 1][k0 + q][lane * NS];
 #pragma unroll
                 for (int j = 0; j < NS; j += 2) {
                     const double2 v = *reinterpret_cast<const double2*>(src + j);
@@ -540,33 +643,20 @@ __global__ __launch_bounds__(192) void ctc_lattice1_kernel(
             for (int j = 0; j < NS; ++j) y[kRescale - 1][j] = ldexp(y[kRescale - 1][j], -dp);
 #pragma unroll
             for (int q = 0; q < kRescale; ++q) {
-                if (q < nb) {
-                    const int t = dir ? Tb - 1 - i : i;
-                    const double p1 = lane_shr1(a[NS - 1]);
-                    double n_[NS];
-#pragma unroll
-                    for (int j = 0; j < NS; ++j) {
-                        // position parity == state parity; s-1 and s-2 of an odd (label) position j are
-                        // a[j-1], a[j-2] (the previous lane's last state for j == 1)
-                        const double x1 = (j >= 1) ? a[j - 1] : p1;
-                        const double x2 = (j >= 2) ? a[j - 2] : p1;
-                        const double base = (j >= 1) ? a[j] + x1 : a[j];   // j >= 1: off the DPP chain
-                        n_[j] = (j & 1) ? fma(skm[j >> 1], x2, base) * y[q][j] : (a[j] + x1) * y[q][j];
-                    }
-#pragma unroll
-                    for (int j = 0; j < NS; ++j) a[j] = n_[j];
-                    if (q == kRescale - 1) E += dp;
-                    if (spill_ok) {
-                        double* orow = out + (int64_t)t * SP + lane * NS;
-#pragma unroll
-                        for (int j = 0; j < NS; j += 2) {
-                            const double hi_ = (e_slot && j == NS - 2) ? (double)E : a[j + 1];
-                            *reinterpret_cast<double2*>(orow + j) = make_double2(a[j], hi_);
-                        }
-                    }
-                    ++i;
-                }
+                step(y[q]);
+                spill();
             }
+            E += dp;
+            ecum[i / kRescale] = (double)E;   // the scale of frame i+3 and of the next block's first three
+            i += kRescale;
+        }
+        for (; k0 < nsteps; ++k0, ++i) {   // tail frames of the sequence: no rescale
+            double yq[NS];
+            const double* src = &s_y[c & 1][k0][lane * NS];
+#pragma unroll
+            for (int j = 0; j < NS; ++j) yq[j] = src[j];
+            step(yq);
+            spill();
         }
     }
     if (dir == 0) {
@@ -595,9 +685,9 @@ __global__ __launch_bounds__(256) void ctc_grad_kernel(
     int label_stride, const int32_t* __restrict__ in_len, const int32_t* __restrict__ lab_len,
     int T, int B, int V, int blank, int Lmax, int RW, int SP, int modeB,
     const float* __restrict__ lse2, const float* __restrict__ rows, const double* __restrict__ alpha,
-    const double* __restrict__ beta_rev, const double* __restrict__ nll2d,
-    const float* __restrict__ nll, float grad_scale, float* __restrict__ grad,
-    float* __restrict__ loss) {
+    const double* __restrict__ beta_rev, const double* __restrict__ aux,
+    const double* __restrict__ nll2d, const float* __restrict__ nll, float grad_scale,
+    float* __restrict__ grad, float* __restrict__ loss) {
     extern __shared__ __attribute__((aligned(16))) float s_occ[];  // [waves][V]
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int wpb = blockDim.x >> 6;
@@ -611,14 +701,26 @@ __global__ __launch_bounds__(256) void ctc_grad_kernel(
     if (!grad) return;
 
     float* occ = s_occ + wave * V;
+    const bool vec = ((V & 3) == 0) && ((st & 3) == 0) && ((sb & 3) == 0) &&
+                     ((reinterpret_cast<uintptr_t>(logits) | reinterpret_cast<uintptr_t>(grad)) & 15) == 0;
     const int64_t nrows = (int64_t)T * B;
     for (int64_t r = (int64_t)blockIdx.x * wpb + wave; r < nrows; r += (int64_t)gridDim.x * wpb) {
         const int b = (int)(r / T), t = (int)(r % T);
         const int Tb = min(max(in_len[b], 0), T);
         float* g = grad + t * st + b * sb;
         if (t >= Tb) {
-            for (int c = lane; c < V; c += 64) g[c] = 0.f;
+            if (vec) {
+                for (int c = lane; c < (V >> 2); c += 64)
+                    reinterpret_cast<float4*>(g)[c] = make_float4(0.f, 0.f, 0.f, 0.f);
+            } else {
+                for (int c = lane; c < V; c += 64) g[c] = 0.f;
+            }
             continue;
+        }
+        if (vec) {
+            for (int c = lane; c < (V >> 2); c += 64) reinterpret_cast<float4*>(occ)[c] = make_float4(0.f, 0.f, 0.f, 0.f);
+        } else {
+            for (int c = lane; c < V; c += 64) occ[c] = 0.f;
         }
         const int L = min(max(lab_len[b], 0), Lmax);
         const int S = 2 * L + 1;
@@ -626,11 +728,19 @@ __global__ __launch_bounds__(256) void ctc_grad_kernel(
         const double* arow = alpha + ((int64_t)b * T + t) * SP;
         const double* brow = beta_rev + ((int64_t)b * T + t) * SP;
         // 2^gexp * alpha_hat * beta_hat / y = the state posterior; slot SP-1 of a row is its scale E
-        const double gexp = nll2d[b] + arow[SP - 1] + brow[SP - 1];
+        // (multi-wave lattices) or, for the single-wave kernel, Ecum[block] of its aux block
+        double gexp = nll2d[b];
+        if (aux) {
+            const int aux_stride = 256 + T / kRescale + 2;
+            const int ka = (t + 1) / kRescale - 1, kb = (Tb - t) / kRescale - 1;   // frame index i: t and Tb-1-t
+            if (ka >= 0) gexp += aux[(int64_t)b * aux_stride + 256 + ka];
+            if (kb >= 0) gexp += aux[((int64_t)B + b) * aux_stride + 256 + kb];
+        } else {
+            gexp += arow[SP - 1] + brow[SP - 1];
+        }
         const float* lrow = rows + ((int64_t)b * T + t) * RW;
         const int64_t* lab = labels + (int64_t)b * label_stride;
 
-        for (int c = lane; c < V; c += 64) occ[c] = 0.f;
         float blank_acc = 0.f;
         for (int s = lane; s < S; s += 64) {
             int cls = blank;
@@ -638,11 +748,11 @@ __global__ __launch_bounds__(256) void ctc_grad_kernel(
             const int ri = modeB ? cls : ((s & 1) ? (s + 1) >> 1 : 0);
             // alpha_hat and beta_hat can each sit ~1000 binary orders below their row maxima where the
             // posterior peaks: multiply mantissas, add exponents, one ldexp
-            const double g = gexp - (double)lrow[ri];
-            const double gn = floor(g);
+            const double gq = gexp - (double)lrow[ri];
+            const double gn = floor(gq);
             int xa, xb;
             const double ma = frexp(arow[s], &xa), mb = frexp(brow[S - 1 - s], &xb);
-            const double pr = ma * mb * (double)__builtin_amdgcn_exp2f((float)(g - gn));
+            const double pr = ma * mb * (double)__builtin_amdgcn_exp2f((float)(gq - gn));
             const double ge = fmax(fmin(gn + (double)(xa + xb), 4000.0), -4000.0);
             const float gam = (float)ldexp(pr, (int)ge);
             if (s & 1) atomicAdd(&occ[cls], gam);
@@ -653,9 +763,22 @@ __global__ __launch_bounds__(256) void ctc_grad_kernel(
         __builtin_amdgcn_wave_barrier();
         const float* z = logits + t * st + b * sb;
         const float l2 = lse2[(int64_t)b * T + t];
-        for (int c = lane; c < V; c += 64) {
-            const float sm = exp2f(z[c] * kLog2e - l2);
-            g[c] = (sm - occ[c]) * scale;
+        if (vec) {
+            const float4* z4 = reinterpret_cast<const float4*>(z);
+            const float4* o4 = reinterpret_cast<const float4*>(occ);
+            float4* g4 = reinterpret_cast<float4*>(g);
+            for (int c = lane; c < (V >> 2); c += 64) {
+                const float4 zz = z4[c], oo = o4[c];
+                g4[c] = make_float4((exp2f(fmaf(zz.x, kLog2e, -l2)) - oo.x) * scale,
+                                    (exp2f(fmaf(zz.y, kLog2e, -l2)) - oo.y) * scale,
+                                    (exp2f(fmaf(zz.z, kLog2e, -l2)) - oo.z) * scale,
+                                    (exp2f(fmaf(zz.w, kLog2e, -l2)) - oo.w) * scale);
+            }
+        } else {
+            for (int c = lane; c < V; c += 64) {
+                const float sm = exp2f(fmaf(z[c], kLog2e, -l2));
+                g[c] = (sm - occ[c]) * scale;
+            }
         }
         __builtin_amdgcn_wave_barrier();
     }
@@ -708,12 +831,19 @@ extern "C" int sp_ctc_fwd_bwd(const float* logits, int64_t stride_t, int64_t str
     float* ws = reinterpret_cast<float*>(workspace);
     const double* dbl = reinterpret_cast<const double*>(ws + d.off_dbl);
     const int64_t nrows = (int64_t)T * B;
-    const int row_blocks = (int)((nrows + 3) / 4 > 4096 ? 4096 : (nrows + 3) / 4);
+    const int row_blocks = (int)((nrows + 3) / 4 > 8192 ? 8192 : (nrows + 3) / 4);
 
     if (T > 0) {
-        hipLaunchKernelGGL(ctc_rows_kernel, dim3(row_blocks), dim3(256), 0, s, logits, stride_t,
-                           stride_b, labels, label_stride, input_lengths, label_lengths, T, B, V,
-                           blank, max_label_len, d.RW, d.modeB, ws + d.off_lse, ws + d.off_rows);
+        const bool vec = (V % 4) == 0 && (stride_t % 4) == 0 && (stride_b % 4) == 0 &&
+                         ((uintptr_t)logits & 15) == 0 && V <= 2048;
+#define SP_ROWS_ARGS logits, stride_t, stride_b, labels, label_stride, input_lengths, label_lengths, T, B, V, \
+                     blank, max_label_len, d.RW, d.modeB, ws + d.off_lse, ws + d.off_rows
+        if (vec && V <= 256) hipLaunchKernelGGL((ctc_rows_vec_kernel<1>), dim3(row_blocks), dim3(256), 0, s, SP_ROWS_ARGS);
+        else if (vec && V <= 512) hipLaunchKernelGGL((ctc_rows_vec_kernel<2>), dim3(row_blocks), dim3(256), 0, s, SP_ROWS_ARGS);
+        else if (vec && V <= 1024) hipLaunchKernelGGL((ctc_rows_vec_kernel<4>), dim3(row_blocks), dim3(256), 0, s, SP_ROWS_ARGS);
+        else if (vec) hipLaunchKernelGGL((ctc_rows_vec_kernel<8>), dim3(row_blocks), dim3(256), 0, s, SP_ROWS_ARGS);
+        else hipLaunchKernelGGL(ctc_rows_kernel, dim3(row_blocks), dim3(256), 0, s, SP_ROWS_ARGS);
+#undef SP_ROWS_ARGS
         int rc = check_launch("ctc_rows_kernel");
         if (rc) return rc;
     }
@@ -723,11 +853,13 @@ extern "C" int sp_ctc_fwd_bwd(const float* logits, int64_t stride_t, int64_t str
     if (S <= 128)
         hipLaunchKernelGGL((ctc_lattice1_kernel<2>), dim3(B, 2), dim3(192), 0, s, ws + d.off_rows, labels, label_stride,
                            input_lengths, label_lengths, T, V, blank, max_label_len, d.RW, d.SP, d.modeB, dblw,
-                           dblw + (size_t)B * T * d.SP, dblw + (size_t)2 * B * T * d.SP, nll);
+                           dblw + (size_t)B * T * d.SP, reinterpret_cast<double*>(ws + d.off_aux),
+                           dblw + (size_t)2 * B * T * d.SP, nll);
     else if (S <= 256)
         hipLaunchKernelGGL((ctc_lattice1_kernel<4>), dim3(B, 2), dim3(192), 0, s, ws + d.off_rows, labels, label_stride,
                            input_lengths, label_lengths, T, V, blank, max_label_len, d.RW, d.SP, d.modeB, dblw,
-                           dblw + (size_t)B * T * d.SP, dblw + (size_t)2 * B * T * d.SP, nll);
+                           dblw + (size_t)B * T * d.SP, reinterpret_cast<double*>(ws + d.off_aux),
+                           dblw + (size_t)2 * B * T * d.SP, nll);
     else if (S <= 512) launch_lattice<2, 4>(d, ws, labels, label_stride, input_lengths, label_lengths, blank, nll, s);
     else if (S <= 1024) launch_lattice<4, 4>(d, ws, labels, label_stride, input_lengths, label_lengths, blank, nll, s);
     else launch_lattice<4, 8>(d, ws, labels, label_stride, input_lengths, label_lengths, blank, nll, s);
@@ -740,7 +872,9 @@ extern "C" int sp_ctc_fwd_bwd(const float* logits, int64_t stride_t, int64_t str
         hipLaunchKernelGGL(ctc_grad_kernel, dim3(gb), dim3(256), lds, s, logits, stride_t, stride_b,
                            labels, label_stride, input_lengths, label_lengths, T, B, V, blank,
                            max_label_len, d.RW, d.SP, d.modeB, ws + d.off_lse, ws + d.off_rows,
-                           dbl, dbl + (size_t)B * T * d.SP, dbl + (size_t)2 * B * T * d.SP, nll,
+                           dbl, dbl + (size_t)B * T * d.SP,
+                           S <= 256 ? reinterpret_cast<const double*>(ws + d.off_aux) : nullptr,
+                           dbl + (size_t)2 * B * T * d.SP, nll,
                            grad_scale, T > 0 ? grad : nullptr, loss);
         rc = check_launch("ctc_grad_kernel");
         if (rc) return rc;

@@ -39,14 +39,23 @@ struct MelPlan {
     float fbt[kMaxBlk][64];  // A operand images: lane l -> fb[k0 + 4 blk + (l>>4)][16 tile + (l&15)]
 };
 
+// Per-wave LDS: the 200-point complex intermediate of 8 frames; after phase 3 has pulled it into
+// registers the same bytes hold the 8 x 201 magnitudes (12.8 KB per wave, 51 KB per block, three
+// blocks per CU).
 struct WaveLds {
-    cf yz[kF][200];
-    float mag[kF][kMagStride];
+    union {
+        cf yz[kF][200];
+        float mag[kF][kMagStride];
+    };
 };
 
 using f32x4 = __attribute__((ext_vector_type(4))) float;
 
-__global__ __launch_bounds__(64 * kWPB, 2) void melspec_kernel(
+// The kernel is latency-bound, not issue-bound (one wave runs ~2.7 k instructions on 8 frames, the
+// chip holds 3 waves per SIMD): every phase therefore issues all of its loads before its first use
+// (straight-line code, registers instead of occupancy), and the mel projection runs its A-operand
+// loads eight MFMAs ahead in a register ring.
+__global__ __launch_bounds__(64 * kWPB, 3) void melspec_kernel(
     const float* __restrict__ wav, const int64_t* __restrict__ offs, int T_max,
     const MelPlan* __restrict__ plan, const int32_t* __restrict__ masks, int flags,
     float* __restrict__ out) {
@@ -71,39 +80,57 @@ __global__ __launch_bounds__(64 * kWPB, 2) void melspec_kernel(
     }
 
     // ------------------------------------------------------------------ phase 1
+    // 200 lane-tasks (frame, n2) in 4 passes; the 16 samples and 16 window taps of ALL passes are
+    // requested first (interior waves: pairs are adjacent floats), then the passes compute.
     const bool interior = (t0 * kHop - kNfft / 2 >= 0) && ((t0 + kF - 1) * kHop + kNfft / 2 <= N) &&
                           (t0 + kF <= Tb);
-#pragma unroll 1
-    for (int p = 0; p < 4; ++p) {
-        const int task = p * 64 + lane;
-        if (task < kF * 25) {
+    {
+        float xs[4][16];
+#pragma unroll
+        for (int p = 0; p < 4; ++p) {
+            const int task = min(p * 64 + lane, kF * 25 - 1);
             const int f = task / 25, n2 = task - f * 25;
             const int t = t0 + f;
-            cf z[8];
             const int base = t * kHop - kNfft / 2 + 2 * n2;
             if (interior) {
 #pragma unroll
                 for (int n1 = 0; n1 < 8; ++n1) {
-                    const int m2 = 50 * n1 + 2 * n2;
-                    const float2 w = *reinterpret_cast<const float2*>(&plan->win[m2]);
-                    z[n1] = mk(x[base + 50 * n1] * w.x, x[base + 50 * n1 + 1] * w.y);
+                    xs[p][2 * n1] = x[base + 50 * n1];
+                    xs[p][2 * n1 + 1] = x[base + 50 * n1 + 1];
                 }
             } else {
                 const bool live = t < Tb;
 #pragma unroll
                 for (int n1 = 0; n1 < 8; ++n1) {
-                    const int m2 = 50 * n1 + 2 * n2;
-                    const float2 w = *reinterpret_cast<const float2*>(&plan->win[m2]);
                     int i0 = reflect(base + 50 * n1, N), i1 = reflect(base + 50 * n1 + 1, N);
                     i0 = min(max(i0, 0), N - 1);
                     i1 = min(max(i1, 0), N - 1);
-                    z[n1] = live ? mk(x[i0] * w.x, x[i1] * w.y) : mk(0.f, 0.f);
+                    const float v0 = x[i0], v1 = x[i1];
+                    xs[p][2 * n1] = live ? v0 : 0.f;
+                    xs[p][2 * n1 + 1] = live ? v1 : 0.f;
                 }
             }
-            dft8(z);
-            L.yz[f][n2] = z[0];
+        }
 #pragma unroll
-            for (int k1 = 1; k1 < 8; ++k1) L.yz[f][k1 * 25 + n2] = mul(z[k1], plan->tw200[n2][k1]);
+        for (int p = 0; p < 4; ++p) {
+            const int task = p * 64 + lane;
+            const int tk = min(task, kF * 25 - 1);
+            const int f = tk / 25, n2 = tk - f * 25;
+            cf z[8];
+#pragma unroll
+            for (int n1 = 0; n1 < 8; ++n1) {
+                const float2 w = *reinterpret_cast<const float2*>(&plan->win[50 * n1 + 2 * n2]);
+                z[n1] = mk(xs[p][2 * n1] * w.x, xs[p][2 * n1 + 1] * w.y);
+            }
+            cf tw[8];
+#pragma unroll
+            for (int k1 = 1; k1 < 8; ++k1) tw[k1] = plan->tw200[n2][k1];
+            dft8(z);
+            if (task < kF * 25) {
+                L.yz[f][n2] = z[0];
+#pragma unroll
+                for (int k1 = 1; k1 < 8; ++k1) L.yz[f][k1 * 25 + n2] = mul(z[k1], tw[k1]);
+            }
         }
     }
     __builtin_amdgcn_wave_barrier();
@@ -122,16 +149,34 @@ __global__ __launch_bounds__(64 * kWPB, 2) void melspec_kernel(
     __builtin_amdgcn_wave_barrier();
 
     // ------------------------------------------------------------------ phase 3
-#pragma unroll 1
-    for (int q = 0; q < 13; ++q) {
-        const int task = q * 64 + lane;
-        if (task < kF * 101) {
+    // 808 lane-tasks (frame, k <= 100) in 13 passes.  Every pass's two spectrum points and its
+    // twiddle are read first; only then do the magnitudes overwrite the same LDS bytes.
+    {
+        constexpr int NP = 13;
+        cf zk[NP], zm[NP], tw[NP];
+#pragma unroll
+        for (int q = 0; q < NP; ++q) {
+            const int task = min(q * 64 + lane, kF * 101 - 1);
             const int f = task / 101, k = task - f * 101;
             const int km = (k == 0) ? 0 : 200 - k;
+            zk[q] = L.yz[f][k];
+            zm[q] = L.yz[f][km];
+            tw[q] = plan->tw400[k];
+        }
+        __builtin_amdgcn_wave_barrier();
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // all reads landed before the aliasing writes
+        __builtin_amdgcn_wave_barrier();
+#pragma unroll
+        for (int q = 0; q < NP; ++q) {
+            const int task = q * 64 + lane;
+            const int tk = min(task, kF * 101 - 1);
+            const int f = tk / 101, k = tk - f * 101;
             float mk_, mm_;
-            real_post(L.yz[f][k], L.yz[f][km], plan->tw400[k], mk_, mm_);
-            L.mag[f][k] = mk_;
-            L.mag[f][200 - k] = mm_;
+            real_post(zk[q], zm[q], tw[q], mk_, mm_);
+            if (task < kF * 101) {
+                L.mag[f][k] = mk_;
+                L.mag[f][200 - k] = mm_;
+            }
         }
     }
     __builtin_amdgcn_wave_barrier();
@@ -146,16 +191,27 @@ __global__ __launch_bounds__(64 * kWPB, 2) void melspec_kernel(
     const float* magrow = L.mag[fcol & 7];
     const int t = t0 + (fcol & 7);
     const bool tmask = (t >= Tb) || (t >= mt0 && t < mt0 + mtw);
+    constexpr int RING = 8;
 #pragma unroll 1
     for (int tile = 0; tile < kTiles; ++tile) {
         const int nblk = plan->tile_nblk[tile];
         const int k0 = plan->tile_k0[tile];
         const float* a_img = plan->fbt[plan->tile_blk0[tile]] + lane;
         f32x4 acc = {0.f, 0.f, 0.f, 0.f};
-        for (int kb = 0; kb < nblk; ++kb) {
-            const float av = a_img[kb * 64];
-            const float bv = magrow[min(k0 + 4 * kb + kq, kBins - 1)];
-            acc = __builtin_amdgcn_mfma_f32_16x16x4f32(av, bv, acc, 0, 0, 0);
+        float ar[RING];
+#pragma unroll
+        for (int r = 0; r < RING; ++r) ar[r] = a_img[min(r, max(nblk - 1, 0)) * 64];
+        for (int kb0 = 0; kb0 < nblk; kb0 += RING) {
+#pragma unroll
+            for (int r = 0; r < RING; ++r) {
+                const int kb = kb0 + r;
+                const float av = ar[r];
+                ar[r] = a_img[min(kb + RING, nblk - 1) * 64];   // eight MFMAs ahead
+                if (kb < nblk) {
+                    const float bv = magrow[min(k0 + 4 * kb + kq, kBins - 1)];
+                    acc = __builtin_amdgcn_mfma_f32_16x16x4f32(av, bv, acc, 0, 0, 0);
+                }
+            }
         }
         if (fcol < kF && t < T_max) {
 #pragma unroll

@@ -80,17 +80,24 @@ __global__ __launch_bounds__(64 * kWPB, 3) void melspec_kernel(
     }
 
     // ------------------------------------------------------------------ phase 1
-    // 200 lane-tasks (frame, n2) in 4 passes; the 16 samples and 16 window taps of ALL passes are
-    // requested first (interior waves: pairs are adjacent floats), then the passes compute.
+    // 200 lane-tasks (frame, n2): lane = (frame parity, n2) and 4 passes walk the frame pairs, so a
+    // lane's 16 window taps and 7 twiddles are loaded once; the 16 samples of ALL passes are
+    // requested before the first butterfly (interior waves: plain indices, no reflection).
+    int mf0 = 0, mfw = 0, mt0 = 0, mtw = 0;
+    if (masks) {
+        mf0 = masks[b * 4 + 0]; mfw = masks[b * 4 + 1];
+        mt0 = masks[b * 4 + 2]; mtw = masks[b * 4 + 3];
+    }
     const bool interior = (t0 * kHop - kNfft / 2 >= 0) && ((t0 + kF - 1) * kHop + kNfft / 2 <= N) &&
                           (t0 + kF <= Tb);
     {
+        const int fh = lane >= 25 ? 1 : 0;
+        const int n2 = min(lane - 25 * fh, 24);
+        const bool active = lane < 50;
         float xs[4][16];
 #pragma unroll
         for (int p = 0; p < 4; ++p) {
-            const int task = min(p * 64 + lane, kF * 25 - 1);
-            const int f = task / 25, n2 = task - f * 25;
-            const int t = t0 + f;
+            const int t = t0 + 2 * p + fh;
             const int base = t * kHop - kNfft / 2 + 2 * n2;
             if (interior) {
 #pragma unroll
@@ -111,22 +118,20 @@ __global__ __launch_bounds__(64 * kWPB, 3) void melspec_kernel(
                 }
             }
         }
+        float2 w[8];
+        cf tw[8];
+#pragma unroll
+        for (int n1 = 0; n1 < 8; ++n1) w[n1] = *reinterpret_cast<const float2*>(&plan->win[50 * n1 + 2 * n2]);
+#pragma unroll
+        for (int k1 = 1; k1 < 8; ++k1) tw[k1] = plan->tw200[n2][k1];
 #pragma unroll
         for (int p = 0; p < 4; ++p) {
-            const int task = p * 64 + lane;
-            const int tk = min(task, kF * 25 - 1);
-            const int f = tk / 25, n2 = tk - f * 25;
+            const int f = 2 * p + fh;
             cf z[8];
 #pragma unroll
-            for (int n1 = 0; n1 < 8; ++n1) {
-                const float2 w = *reinterpret_cast<const float2*>(&plan->win[50 * n1 + 2 * n2]);
-                z[n1] = mk(xs[p][2 * n1] * w.x, xs[p][2 * n1 + 1] * w.y);
-            }
-            cf tw[8];
-#pragma unroll
-            for (int k1 = 1; k1 < 8; ++k1) tw[k1] = plan->tw200[n2][k1];
+            for (int n1 = 0; n1 < 8; ++n1) z[n1] = mk(xs[p][2 * n1] * w[n1].x, xs[p][2 * n1 + 1] * w[n1].y);
             dft8(z);
-            if (task < kF * 25) {
+            if (active) {
                 L.yz[f][n2] = z[0];
 #pragma unroll
                 for (int k1 = 1; k1 < 8; ++k1) L.yz[f][k1 * 25 + n2] = mul(z[k1], tw[k1]);
@@ -182,45 +187,62 @@ __global__ __launch_bounds__(64 * kWPB, 3) void melspec_kernel(
     __builtin_amdgcn_wave_barrier();
 
     // ------------------------------------------------------------------ phases 4 + 5
-    int mf0 = 0, mfw = 0, mt0 = 0, mtw = 0;
-    if (masks) {
-        mf0 = masks[b * 4 + 0]; mfw = masks[b * 4 + 1];
-        mt0 = masks[b * 4 + 2]; mtw = masks[b * 4 + 3];
-    }
-    const int fcol = lane & 15, kq = lane >> 4;
-    const float* magrow = L.mag[fcol & 7];
-    const int t = t0 + (fcol & 7);
-    const bool tmask = (t >= Tb) || (t >= mt0 && t < mt0 + mtw);
-    constexpr int RING = 8;
-#pragma unroll 1
-    for (int tile = 0; tile < kTiles; ++tile) {
-        const int nblk = plan->tile_nblk[tile];
-        const int k0 = plan->tile_k0[tile];
-        const float* a_img = plan->fbt[plan->tile_blk0[tile]] + lane;
-        f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+    // One flat pass over the non-zero 4-bin blocks of all five 16-mel tiles (they are contiguous in
+    // plan->fbt), A operands running eight MFMAs ahead in a register ring across tile boundaries;
+    // a tile's 16 x 8 outputs are masked and stored when its last block has been accumulated.
+    {
+        const int fcol = lane & 15, kq = lane >> 4;
+        const float* magrow = L.mag[fcol & 7];
+        const int t = t0 + (fcol & 7);
+        const bool tmask = (t >= Tb) || (t >= mt0 && t < mt0 + mtw);
+        const bool store_lane = fcol < kF && t < T_max;
+        int tnb[kTiles], tk0[kTiles];
+#pragma unroll
+        for (int i = 0; i < kTiles; ++i) { tnb[i] = plan->tile_nblk[i]; tk0[i] = plan->tile_k0[i]; }
+        const int total = plan->tile_blk0[kTiles - 1] + tnb[kTiles - 1];
+        const float* a_img = plan->fbt[0] + lane;
+        constexpr int RING = 8;
         float ar[RING];
 #pragma unroll
-        for (int r = 0; r < RING; ++r) ar[r] = a_img[min(r, max(nblk - 1, 0)) * 64];
-        for (int kb0 = 0; kb0 < nblk; kb0 += RING) {
+        for (int r = 0; r < RING; ++r) ar[r] = a_img[min(r, max(total - 1, 0)) * 64];
+        f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+        int tile = 0, left = tnb[0], kbase = tk0[0];
+        auto flush = [&]() {
+            if (store_lane) {
 #pragma unroll
-            for (int r = 0; r < RING; ++r) {
-                const int kb = kb0 + r;
-                const float av = ar[r];
-                ar[r] = a_img[min(kb + RING, nblk - 1) * 64];   // eight MFMAs ahead
-                if (kb < nblk) {
-                    const float bv = magrow[min(k0 + 4 * kb + kq, kBins - 1)];
-                    acc = __builtin_amdgcn_mfma_f32_16x16x4f32(av, bv, acc, 0, 0, 0);
+                for (int r = 0; r < 4; ++r) {
+                    const int mel = tile * 16 + kq * 4 + r;
+                    float v = acc[r];
+                    if (flags & 1) v = logf(v + 1e-6f);
+                    if (tmask || (mel >= mf0 && mel < mf0 + mfw)) v = 0.f;
+                    outb[(int64_t)mel * T_max + t] = v;
                 }
             }
-        }
-        if (fcol < kF && t < T_max) {
+            acc = f32x4{0.f, 0.f, 0.f, 0.f};
+            ++tile;
+            // tile metadata by select chain (register arrays must not be indexed at run time)
+            int nb = 0, k0n = 0;
 #pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const int mel = tile * 16 + kq * 4 + r;
-                float v = acc[r];
-                if (flags & 1) v = logf(v + 1e-6f);
-                if (tmask || (mel >= mf0 && mel < mf0 + mfw)) v = 0.f;
-                outb[(int64_t)mel * T_max + t] = v;
+            for (int i = 1; i < kTiles; ++i) { nb = tile == i ? tnb[i] : nb; k0n = tile == i ? tk0[i] : k0n; }
+            left = nb;
+            kbase = k0n;
+        };
+        while (tile < kTiles && left == 0) flush();   // leading all-zero tiles
+        for (int g0 = 0; g0 < total; g0 += RING) {
+#pragma unroll
+            for (int r = 0; r < RING; ++r) {
+                const int g = g0 + r;
+                const float av = ar[r];
+                ar[r] = a_img[min(g + RING, total - 1) * 64];   // eight MFMAs ahead
+                if (g < total) {
+                    const float bv = magrow[min(kbase + kq, kBins - 1)];
+                    acc = __builtin_amdgcn_mfma_f32_16x16x4f32(av, bv, acc, 0, 0, 0);
+                    kbase += 4;
+                    if (--left == 0) {
+                        flush();
+                        while (tile < kTiles && left == 0) flush();   // all-zero tiles store zeros
+                    }
+                }
             }
         }
     }

@@ -86,6 +86,7 @@ __global__ __launch_bounds__(256, 2) void conv3x5_kernel(
     const float* __restrict__ bias, const __hip_bfloat16* __restrict__ epi_src,
     const float* __restrict__ epi_coef, int B, int F, int T, __hip_bfloat16* __restrict__ out) {
     __shared__ __attribute__((aligned(16))) __hip_bfloat16 tile[kRows * kPW * kPStr];
+    __shared__ __attribute__((aligned(16))) __hip_bfloat16 otile[kFR * kTP * kPStr];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int r = lane & 31, h = lane >> 5;
     const int t0 = blockIdx.x * kTP, f0 = blockIdx.y * kFR, b = blockIdx.z;
@@ -103,32 +104,48 @@ __global__ __launch_bounds__(256, 2) void conv3x5_kernel(
                 c2[j] = (IN_MODE == IN_BNBWD) ? coef[64 + ch4 * 8 + j] : 0.f;
             }
         }
-#pragma unroll 1
-        for (int id = tid; id < kRows * kPW * 4; id += 256) {
+        // all of the strip's loads are issued before the first is used (7 x 16 bytes per thread, 14 in
+        // the BN-backward mode): one HBM round trip per block instead of seven
+        constexpr int NIT = (kRows * kPW * 4 + 255) / 256;
+        uint4 v[NIT], v2[NIT];
+        bool ok[NIT];
+#pragma unroll
+        for (int it = 0; it < NIT; ++it) {
+            const int id = tid + it * 256;
             const int row = id / (kPW * 4);
             const int pos = (id - row * (kPW * 4)) >> 2;
             const int f = f0 - 1 + row, t = t0 - 2 + pos;
-            uint4 v = make_uint4(0, 0, 0, 0);
-            if (f >= 0 && f < F && t >= 0 && t < T) {
+            ok[it] = id < kRows * kPW * 4 && f >= 0 && f < F && t >= 0 && t < T;
+            v[it] = make_uint4(0, 0, 0, 0);
+            v2[it] = make_uint4(0, 0, 0, 0);
+            if (ok[it]) {
                 const int64_t off = ((img + (int64_t)f * T + t) * kC + ch4 * 8);
-                v = *reinterpret_cast<const uint4*>(in + off);
-                if (IN_MODE == IN_BNRELU) {
-                    float x[8];
-                    unpack8(v, x);
-#pragma unroll
-                    for (int j = 0; j < 8; ++j) x[j] = fmaxf(0.f, c0[j] * x[j] + c1[j]);
-                    v = pack8(x);
-                } else if (IN_MODE == IN_BNBWD) {
-                    const uint4 v2 = *reinterpret_cast<const uint4*>(in2 + off);
-                    float x[8], y[8];
-                    unpack8(v, x);
-                    unpack8(v2, y);
-#pragma unroll
-                    for (int j = 0; j < 8; ++j) x[j] = c0[j] * x[j] + c1[j] * y[j] + c2[j];
-                    v = pack8(x);
-                }
+                v[it] = *reinterpret_cast<const uint4*>(in + off);
+                if (IN_MODE == IN_BNBWD) v2[it] = *reinterpret_cast<const uint4*>(in2 + off);
             }
-            *reinterpret_cast<uint4*>(tile + (row * kPW + pos) * kPStr + ch4 * 8) = v;
+        }
+#pragma unroll
+        for (int it = 0; it < NIT; ++it) {
+            const int id = tid + it * 256;
+            const int row = id / (kPW * 4);
+            const int pos = (id - row * (kPW * 4)) >> 2;
+            uint4 o = v[it];
+            if (IN_MODE == IN_BNRELU) {
+                float x[8];
+                unpack8(o, x);
+#pragma unroll
+                for (int j = 0; j < 8; ++j) x[j] = fmaxf(0.f, c0[j] * x[j] + c1[j]);
+                o = pack8(x);
+            } else if (IN_MODE == IN_BNBWD) {
+                float x[8], y[8];
+                unpack8(o, x);
+                unpack8(v2[it], y);
+#pragma unroll
+                for (int j = 0; j < 8; ++j) x[j] = c0[j] * x[j] + c1[j] * y[j] + c2[j];
+                o = pack8(x);
+            }
+            if (!ok[it]) o = make_uint4(0, 0, 0, 0);   // zero padding is applied AFTER the transform
+            if (id < kRows * kPW * 4) *reinterpret_cast<uint4*>(tile + (row * kPW + pos) * kPStr + ch4 * 8) = o;
         }
     }
     // ---- weights: the whole 32x480 matrix in registers (30 fragments) ----
@@ -162,31 +179,52 @@ __global__ __launch_bounds__(256, 2) void conv3x5_kernel(
         }
     }
     if (f >= F) return;
-    // ---- epilogue: lane = position (column), registers = output channels 8g + 4h + i ----
+    // ---- epilogue ----
+    // The MFMA leaves lane = position, registers = 16 of its channels (8g + 4h + i): stored directly
+    // that is 8 bytes per lane into 32 different cache lines per instruction.  Each wave therefore
+    // transposes its 64 x 32 output through its own LDS slab and then works in 16-byte chunks
+    // (4 lanes = one position's 64 bytes, consecutive positions in consecutive lanes): epilogue
+    // source loads and output stores are 1 KiB contiguous per instruction.
+    __hip_bfloat16* slab = otile + wave * (kTP * kPStr);
 #pragma unroll
     for (int m = 0; m < 2; ++m) {
-        const int t = t0 + m * 32 + r;
-        if (t >= T) continue;
-        const int64_t base = (img + (int64_t)f * T + t) * kC;
 #pragma unroll
-        for (int g = 0; g < 4; ++g) {
-            const int co = 8 * g + 4 * h;
-            float v[4] = {acc[m][4 * g], acc[m][4 * g + 1], acc[m][4 * g + 2], acc[m][4 * g + 3]};
+        for (int g = 0; g < 4; ++g)
+            *reinterpret_cast<uint2*>(slab + (m * 32 + r) * kPStr + 8 * g + 4 * h) =
+                pack4(acc[m][4 * g], acc[m][4 * g + 1], acc[m][4 * g + 2], acc[m][4 * g + 3]);
+    }
+    __builtin_amdgcn_wave_barrier();
+    {
+        const int ch4 = lane & 3;
+        float e0[8], e1[8];
+        if (EPI == EPI_MASK) {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) { e0[j] = epi_coef[ch4 * 8 + j]; e1[j] = epi_coef[32 + ch4 * 8 + j]; }
+        }
+        uint4 ev[4];
+#pragma unroll
+        for (int it = 0; it < 4; ++it) {
+            const int pos = it * 16 + (lane >> 2), t = t0 + pos;
+            ev[it] = make_uint4(0, 0, 0, 0);
+            if (EPI != EPI_NONE && t < T)
+                ev[it] = *reinterpret_cast<const uint4*>(epi_src + (img + (int64_t)f * T + t) * kC + ch4 * 8);
+        }
+#pragma unroll
+        for (int it = 0; it < 4; ++it) {
+            const int pos = it * 16 + (lane >> 2), t = t0 + pos;
+            uint4 o = *reinterpret_cast<const uint4*>(slab + pos * kPStr + ch4 * 8);
             if (EPI != EPI_NONE) {
-                const uint2 e = *reinterpret_cast<const uint2*>(epi_src + base + co);
-                const float e4[4] = {__uint_as_float(e.x << 16), __uint_as_float(e.x & 0xFFFF0000u),
-                                     __uint_as_float(e.y << 16), __uint_as_float(e.y & 0xFFFF0000u)};
+                float v[8], e[8];
+                unpack8(o, v);
+                unpack8(ev[it], e);
 #pragma unroll
-                for (int i = 0; i < 4; ++i) {
-                    if (EPI == EPI_MASK) {
-                        const bool keep = epi_coef[co + i] * e4[i] + epi_coef[32 + co + i] > 0.f;
-                        v[i] = keep ? v[i] : 0.f;
-                    } else {
-                        v[i] += e4[i];
-                    }
+                for (int j = 0; j < 8; ++j) {
+                    if (EPI == EPI_MASK) v[j] = (e0[j] * e[j] + e1[j] > 0.f) ? v[j] : 0.f;
+                    else v[j] += e[j];
                 }
+                o = pack8(v);
             }
-            *reinterpret_cast<uint2*>(out + base + co) = pack4(v[0], v[1], v[2], v[3]);
+            if (t < T) *reinterpret_cast<uint4*>(out + (img + (int64_t)f * T + t) * kC + ch4 * 8) = o;
         }
     }
 }
@@ -421,14 +459,31 @@ __global__ __launch_bounds__(256) void bn_reduce_kernel(const __hip_bfloat16* __
     float acc[16];
 #pragma unroll
     for (int i = 0; i < 16; ++i) acc[i] = 0.f;
-    for (int64_t c = (int64_t)blockIdx.x * 256 + threadIdx.x; c < n * 4; c += (int64_t)gridDim.x * 256) {
-        float a[8], bv[8];
-        unpack8(*reinterpret_cast<const uint4*>(p0 + c * 8), a);
-        if (MODE == 1) unpack8(*reinterpret_cast<const uint4*>(p1 + c * 8), bv);
+    // four independent 16-byte loads in flight per thread; the grid is small (reduce_blocks) because
+    // every block ends in 64 same-address atomics
+    const int64_t stride = (int64_t)gridDim.x * 256, total = n * 4;
+    for (int64_t c0 = (int64_t)blockIdx.x * 256 + threadIdx.x; c0 < total; c0 += 4 * stride) {
+        uint4 ra[4], rb[4];
 #pragma unroll
-        for (int j = 0; j < 8; ++j) {
-            acc[j] += a[j];
-            acc[8 + j] += (MODE == 0) ? a[j] * a[j] : a[j] * bv[j];
+        for (int u = 0; u < 4; ++u) {
+            const int64_t c = c0 + u * stride;
+            ra[u] = make_uint4(0, 0, 0, 0);
+            rb[u] = make_uint4(0, 0, 0, 0);
+            if (c < total) {
+                ra[u] = *reinterpret_cast<const uint4*>(p0 + c * 8);
+                if (MODE == 1) rb[u] = *reinterpret_cast<const uint4*>(p1 + c * 8);
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            float a[8], bv[8];
+            unpack8(ra[u], a);
+            if (MODE == 1) unpack8(rb[u], bv);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                acc[j] += a[j];
+                acc[8 + j] += (MODE == 0) ? a[j] * a[j] : a[j] * bv[j];
+            }
         }
     }
     reduce_ch4<16>(acc);
@@ -516,6 +571,7 @@ __global__ __launch_bounds__(256) void block_out_kernel(const __hip_bfloat16* __
 }
 
 // g2pre = gz * [z > 0] (gz, z in the strided layout), sums += (sum g2pre, sum g2pre*y2)
+template <bool DENSE>
 __global__ __launch_bounds__(256) void block_bwd_in_kernel(const __hip_bfloat16* __restrict__ gz,
                                                            const __hip_bfloat16* __restrict__ z, Strides zs,
                                                            const __hip_bfloat16* __restrict__ y2, int B, int F,
@@ -526,23 +582,45 @@ __global__ __launch_bounds__(256) void block_bwd_in_kernel(const __hip_bfloat16*
     float acc[16];
 #pragma unroll
     for (int i = 0; i < 16; ++i) acc[i] = 0.f;
-    const int64_t n = (int64_t)B * F * T;
-    for (int64_t c = (int64_t)blockIdx.x * 256 + threadIdx.x; c < n * 4; c += (int64_t)gridDim.x * 256) {
-        const int64_t p = c >> 2;
-        const int t = (int)(p % T);
-        const int64_t bf = p / T;
-        const int64_t off = (bf / F) * zs.sb + (bf % F) * zs.sf + (int64_t)t * zs.st + ch4 * 8;
-        float gv[8], zv[8], yv[8];
-        unpack8(*reinterpret_cast<const uint4*>(gz + off), gv);
-        unpack8(*reinterpret_cast<const uint4*>(z + off), zv);
-        unpack8(*reinterpret_cast<const uint4*>(y2 + c * 8), yv);
+    const uint32_t total = (uint32_t)B * F * T * 4;   // host checks < 2^31
+    const uint32_t stride = gridDim.x * 256;
+    for (uint32_t c0 = blockIdx.x * 256 + threadIdx.x; c0 < total; c0 += 2 * stride) {
+        uint4 rg[2], rz[2], ry[2];
+        bool ok[2];
 #pragma unroll
-        for (int j = 0; j < 8; ++j) {
-            gv[j] = zv[j] > 0.f ? gv[j] : 0.f;
-            acc[j] += gv[j];
-            acc[8 + j] += gv[j] * yv[j];
+        for (int u = 0; u < 2; ++u) {
+            const uint32_t c = c0 + u * stride;
+            ok[u] = c < total;
+            rg[u] = rz[u] = ry[u] = make_uint4(0, 0, 0, 0);
+            if (ok[u]) {
+                int64_t off;
+                if (DENSE) {
+                    off = (int64_t)c * 8;
+                } else {
+                    const uint32_t p = c >> 2;
+                    const uint32_t bf = p / (uint32_t)T, t = p - bf * (uint32_t)T;
+                    const uint32_t bb = bf / (uint32_t)F, f = bf - bb * (uint32_t)F;
+                    off = bb * zs.sb + f * zs.sf + (int64_t)t * zs.st + ch4 * 8;
+                }
+                rg[u] = *reinterpret_cast<const uint4*>(gz + off);
+                rz[u] = *reinterpret_cast<const uint4*>(z + off);
+                ry[u] = *reinterpret_cast<const uint4*>(y2 + (int64_t)c * 8);
+            }
         }
-        *reinterpret_cast<uint4*>(gpre + c * 8) = pack8(gv);
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            float gv[8], zv[8], yv[8];
+            unpack8(rg[u], gv);
+            unpack8(rz[u], zv);
+            unpack8(ry[u], yv);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                gv[j] = zv[j] > 0.f ? gv[j] : 0.f;
+                acc[j] += gv[j];
+                acc[8 + j] += gv[j] * yv[j];
+            }
+            if (ok[u]) *reinterpret_cast<uint4*>(gpre + (int64_t)(c0 + u * stride) * 8) = pack8(gv);
+        }
     }
     reduce_ch4<16>(acc);
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -556,6 +634,14 @@ __global__ __launch_bounds__(256) void block_bwd_in_kernel(const __hip_bfloat16*
         const float sm = red[0][c4][k] + red[1][c4][k] + red[2][c4][k] + red[3][c4][k];
         atomicAdd(sums + (k >> 3) * 32 + c4 * 8 + (k & 7), sm);
     }
+}
+
+// grid of the reducing kernels: every block ends in 64 same-address atomics, so few and fat blocks
+static int reduce_blocks(int64_t chunks) {
+    int64_t b = (chunks + 1023) / 1024;
+    if (b > 1024) b = 1024;
+    if (b < 1) b = 1;
+    return (int)b;
 }
 
 static int stream_blocks(int64_t chunks) {
@@ -656,7 +742,7 @@ extern "C" int sp_bn_stats(const void* y, int64_t npos, float* sums, void* strea
     hipStream_t s = (hipStream_t)stream;
     hipError_t e = hipMemsetAsync(sums, 0, 64 * sizeof(float), s);
     if (e != hipSuccess) return fail(SP_ELAUNCH, "sp_bn_stats: %s", hipGetErrorString(e));
-    hipLaunchKernelGGL((bn_reduce_kernel<0>), dim3(stream_blocks(npos * 4)), dim3(256), 0, s, (const bf16*)y,
+    hipLaunchKernelGGL((bn_reduce_kernel<0>), dim3(reduce_blocks(npos * 4)), dim3(256), 0, s, (const bf16*)y,
                        (const bf16*)nullptr, npos, sums);
     return check_launch("bn_reduce_kernel<0>");
 }
@@ -666,7 +752,7 @@ extern "C" int sp_bn_bwd_reduce(const void* g, const void* y, int64_t npos, floa
     hipStream_t s = (hipStream_t)stream;
     hipError_t e = hipMemsetAsync(sums, 0, 64 * sizeof(float), s);
     if (e != hipSuccess) return fail(SP_ELAUNCH, "sp_bn_bwd_reduce: %s", hipGetErrorString(e));
-    hipLaunchKernelGGL((bn_reduce_kernel<1>), dim3(stream_blocks(npos * 4)), dim3(256), 0, s, (const bf16*)g,
+    hipLaunchKernelGGL((bn_reduce_kernel<1>), dim3(reduce_blocks(npos * 4)), dim3(256), 0, s, (const bf16*)g,
                        (const bf16*)y, npos, sums);
     return check_launch("bn_reduce_kernel<1>");
 }
@@ -711,7 +797,14 @@ extern "C" int sp_block_bwd_in(const void* gz, const void* z, int64_t zsb, int64
     hipError_t e = hipMemsetAsync(sums, 0, 64 * sizeof(float), s);
     if (e != hipSuccess) return fail(SP_ELAUNCH, "sp_block_bwd_in: %s", hipGetErrorString(e));
     Strides zs{zsb, zsf, zst};
-    hipLaunchKernelGGL(block_bwd_in_kernel, dim3(stream_blocks((int64_t)B * F * T * 4)), dim3(256), 0, s,
-                       (const bf16*)gz, (const bf16*)z, zs, (const bf16*)y2, B, F, T, (bf16*)gpre, sums);
+    SP_CHECK_ARG((int64_t)B * F * T * 4 < ((int64_t)1 << 31), "sp_block_bwd_in: too many positions");
+    const bool dense = zst == 32 && zsf == (int64_t)T * 32 && zsb == (int64_t)F * T * 32;
+    const int nb = reduce_blocks((int64_t)B * F * T * 4);
+    if (dense)
+        hipLaunchKernelGGL((block_bwd_in_kernel<true>), dim3(nb), dim3(256), 0, s, (const bf16*)gz, (const bf16*)z, zs,
+                           (const bf16*)y2, B, F, T, (bf16*)gpre, sums);
+    else
+        hipLaunchKernelGGL((block_bwd_in_kernel<false>), dim3(nb), dim3(256), 0, s, (const bf16*)gz, (const bf16*)z, zs,
+                           (const bf16*)y2, B, F, T, (bf16*)gpre, sums);
     return check_launch("block_bwd_in_kernel");
 }

@@ -9,7 +9,7 @@
 
 namespace sp {
 
-constexpr int kLnMaxChunks = 4;
+constexpr int kLnMaxChunks = 4;   // N <= 2048
 
 template <typename T> struct Vec8;
 template <> struct Vec8<__hip_bfloat16> {
@@ -44,7 +44,36 @@ template <> struct Vec8<float> {
     }
 };
 
-template <typename T>
+// Raw 8-element chunk as it sits in memory (prefetched a row ahead, converted when used).
+template <typename T> struct Raw8;
+template <> struct Raw8<__hip_bfloat16> {
+    uint4 v;
+    __device__ __forceinline__ void load(const __hip_bfloat16* p) { v = *reinterpret_cast<const uint4*>(p); }
+    __device__ __forceinline__ void zero() { v = make_uint4(0, 0, 0, 0); }
+    __device__ __forceinline__ void get(float (&f)[8]) const {
+        const uint32_t w[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            f[2 * i] = __uint_as_float(w[i] << 16);
+            f[2 * i + 1] = __uint_as_float(w[i] & 0xFFFF0000u);
+        }
+    }
+};
+template <> struct Raw8<float> {
+    float4 a, b;
+    __device__ __forceinline__ void load(const float* p) {
+        a = *reinterpret_cast<const float4*>(p);
+        b = *reinterpret_cast<const float4*>(p + 4);
+    }
+    __device__ __forceinline__ void zero() { a = make_float4(0, 0, 0, 0); b = a; }
+    __device__ __forceinline__ void get(float (&f)[8]) const {
+        f[0] = a.x; f[1] = a.y; f[2] = a.z; f[3] = a.w; f[4] = b.x; f[5] = b.y; f[6] = b.z; f[7] = b.w;
+    }
+};
+
+// NCH = chunks of 8 per lane (N <= 512 * NCH).  Every wave walks its rows with the NEXT row's
+// chunks already requested (raw, in registers): a row costs its arithmetic, not an HBM round trip.
+template <typename T, int NCH>
 __global__ __launch_bounds__(256) void ln_fwd_kernel(const T* __restrict__ x, const float* __restrict__ gamma,
                                                      const float* __restrict__ beta, int64_t M, int N, float eps,
                                                      T* __restrict__ y, float* __restrict__ mean_out,
@@ -52,23 +81,31 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(const T* __restrict__ x, co
     const int lane = threadIdx.x & 63;
     const int nchunk = N >> 3;
     const float inv_n = 1.f / (float)N;
-    for (int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6); row < M; row += (int64_t)gridDim.x * 4) {
-        const T* xr = x + row * N;
-        float v[kLnMaxChunks][8];
+    const int64_t rstep = (int64_t)gridDim.x * 4;
+    int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    Raw8<T> nx[NCH];
+#pragma unroll
+    for (int c = 0; c < NCH; ++c) {
+        nx[c].zero();
+        if (row < M && lane + 64 * c < nchunk) nx[c].load(x + row * N + (lane + 64 * c) * 8);
+    }
+    for (; row < M; row += rstep) {
+        float v[NCH][8];
+#pragma unroll
+        for (int c = 0; c < NCH; ++c) nx[c].get(v[c]);
+        const int64_t nrow = row + rstep;
+#pragma unroll
+        for (int c = 0; c < NCH; ++c)
+            if (nrow < M && lane + 64 * c < nchunk) nx[c].load(x + nrow * N + (lane + 64 * c) * 8);
         float s = 0.f;
 #pragma unroll
-        for (int c = 0; c < kLnMaxChunks; ++c) {
-            const int ch = lane + 64 * c;
-            if (ch < nchunk) {
-                Vec8<T>::ld(xr + ch * 8, v[c]);
+        for (int c = 0; c < NCH; ++c)
 #pragma unroll
-                for (int j = 0; j < 8; ++j) s += v[c][j];
-            }
-        }
+            for (int j = 0; j < 8; ++j) s += v[c][j];   // chunks past the row hold zeros
         const float mean = wave_sum(s) * inv_n;
         float q = 0.f;
 #pragma unroll
-        for (int c = 0; c < kLnMaxChunks; ++c)
+        for (int c = 0; c < NCH; ++c)
             if (lane + 64 * c < nchunk) {
 #pragma unroll
                 for (int j = 0; j < 8; ++j) { const float dlt = v[c][j] - mean; q += dlt * dlt; }
@@ -76,19 +113,22 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(const T* __restrict__ x, co
         const float rstd = rsqrtf(wave_sum(q) * inv_n + eps);
         if (lane == 0) { mean_out[row] = mean; rstd_out[row] = rstd; }
 #pragma unroll
-        for (int c = 0; c < kLnMaxChunks; ++c) {
+        for (int c = 0; c < NCH; ++c) {
             const int ch = lane + 64 * c;
             if (ch < nchunk) {
-                float o[8];
+                float gm[8], bt[8], o[8];
+                Raw8<float> rg, rb;
+                rg.load(gamma + ch * 8); rb.load(beta + ch * 8);   // L1-resident
+                rg.get(gm); rb.get(bt);
 #pragma unroll
-                for (int j = 0; j < 8; ++j) o[j] = (v[c][j] - mean) * rstd * gamma[ch * 8 + j] + beta[ch * 8 + j];
+                for (int j = 0; j < 8; ++j) o[j] = (v[c][j] - mean) * rstd * gm[j] + bt[j];
                 Vec8<T>::st(y + row * N + ch * 8, o);
             }
         }
     }
 }
 
-template <typename T>
+template <typename T, int NCH>
 __global__ __launch_bounds__(256) void ln_bwd_kernel(const T* __restrict__ gy, const T* __restrict__ x,
                                                      const float* __restrict__ mean_in,
                                                      const float* __restrict__ rstd_in,
@@ -99,25 +139,47 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const T* __restrict__ gy, c
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int nchunk = N >> 3;
     const float inv_n = 1.f / (float)N;
-    float dg[kLnMaxChunks][8], db[kLnMaxChunks][8], gm[kLnMaxChunks][8];
+    float dg[NCH][8], db[NCH][8], gm[NCH][8];
 #pragma unroll
-    for (int c = 0; c < kLnMaxChunks; ++c)
+    for (int c = 0; c < NCH; ++c)
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
             dg[c][j] = 0.f; db[c][j] = 0.f;
             const int ch = lane + 64 * c;
             gm[c][j] = ch < nchunk ? gamma[ch * 8 + j] : 0.f;
         }
-    for (int64_t row = (int64_t)blockIdx.x * 4 + wave; row < M; row += (int64_t)gridDim.x * 4) {
-        const float mean = mean_in[row], rstd = rstd_in[row];
-        float g[kLnMaxChunks][8], xh[kLnMaxChunks][8];
+    const int64_t rstep = (int64_t)gridDim.x * 4;
+    int64_t row = (int64_t)blockIdx.x * 4 + wave;
+    Raw8<T> ng[NCH], nxr[NCH], nr[NCH];
+    float nmean = 0.f, nrstd = 0.f;
+    auto fetch = [&](int64_t r) {
+        if (r < M) {
+            nmean = mean_in[r];
+            nrstd = rstd_in[r];
+#pragma unroll
+            for (int c = 0; c < NCH; ++c) {
+                const int ch = lane + 64 * c;
+                if (ch < nchunk) {
+                    ng[c].load(gy + r * N + ch * 8);
+                    nxr[c].load(x + r * N + ch * 8);
+                    if (gres) nr[c].load(gres + r * N + ch * 8);
+                }
+            }
+        }
+    };
+#pragma unroll
+    for (int c = 0; c < NCH; ++c) { ng[c].zero(); nxr[c].zero(); nr[c].zero(); }
+    fetch(row);
+    for (; row < M; row += rstep) {
+        const float mean = nmean, rstd = nrstd;
+        float g[NCH][8], xh[NCH][8], o[NCH][8];
+#pragma unroll
+        for (int c = 0; c < NCH; ++c) { ng[c].get(g[c]); nxr[c].get(xh[c]); nr[c].get(o[c]); }
+        fetch(row + rstep);
         float s1 = 0.f, s2 = 0.f;
 #pragma unroll
-        for (int c = 0; c < kLnMaxChunks; ++c) {
-            const int ch = lane + 64 * c;
-            if (ch < nchunk) {
-                Vec8<T>::ld(gy + row * N + ch * 8, g[c]);
-                Vec8<T>::ld(x + row * N + ch * 8, xh[c]);
+        for (int c = 0; c < NCH; ++c) {
+            if (lane + 64 * c < nchunk) {
 #pragma unroll
                 for (int j = 0; j < 8; ++j) {
                     xh[c][j] = (xh[c][j] - mean) * rstd;
@@ -131,24 +193,18 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const T* __restrict__ gy, c
         }
         const float c1 = wave_sum(s1) * inv_n, c2 = wave_sum(s2) * inv_n;
 #pragma unroll
-        for (int c = 0; c < kLnMaxChunks; ++c) {
+        for (int c = 0; c < NCH; ++c) {
             const int ch = lane + 64 * c;
             if (ch < nchunk) {
-                float o[8];
-                if (gres) Vec8<T>::ld(gres + row * N + ch * 8, o);
-                else {
 #pragma unroll
-                    for (int j = 0; j < 8; ++j) o[j] = 0.f;
-                }
-#pragma unroll
-                for (int j = 0; j < 8; ++j) o[j] += rstd * (g[c][j] - c1 - xh[c][j] * c2);
-                Vec8<T>::st(gx + row * N + ch * 8, o);
+                for (int j = 0; j < 8; ++j) o[c][j] += rstd * (g[c][j] - c1 - xh[c][j] * c2);   // o = gres or 0
+                Vec8<T>::st(gx + row * N + ch * 8, o[c]);
             }
         }
     }
     // block reduction of the parameter gradients, then one atomic per column per block
 #pragma unroll
-    for (int c = 0; c < kLnMaxChunks; ++c) {
+    for (int c = 0; c < NCH; ++c) {
         const int ch = lane + 64 * c;
         if (ch < nchunk) {
 #pragma unroll
@@ -183,14 +239,16 @@ extern "C" int sp_layernorm_fwd(const void* x, const float* gamma, const float* 
     if (M == 0) return SP_OK;
     SP_CHECK_ARG(x && gamma && beta && y && mean && rstd, "sp_layernorm_fwd: null pointer");
     int64_t blocks = (M + 3) / 4;
-    if (blocks > 4096) blocks = 4096;
+    if (blocks > 1024) blocks = 1024;
     hipStream_t s = (hipStream_t)stream;
-    if (dtype == SP_F32)
-        hipLaunchKernelGGL((ln_fwd_kernel<float>), dim3((int)blocks), dim3(256), 0, s, (const float*)x, gamma, beta, M, N,
-                           eps, (float*)y, mean, rstd);
-    else
-        hipLaunchKernelGGL((ln_fwd_kernel<__hip_bfloat16>), dim3((int)blocks), dim3(256), 0, s,
-                           (const __hip_bfloat16*)x, gamma, beta, M, N, eps, (__hip_bfloat16*)y, mean, rstd);
+    const int nch = (N + 511) / 512;
+#define SP_LN_FWD(T, NCH) hipLaunchKernelGGL((ln_fwd_kernel<T, NCH>), dim3((int)blocks), dim3(256), 0, s, (const T*)x, \
+                                             gamma, beta, M, N, eps, (T*)y, mean, rstd)
+#define SP_LN_FWD_T(T) { if (nch == 1) SP_LN_FWD(T, 1); else if (nch == 2) SP_LN_FWD(T, 2); \
+                         else if (nch == 3) SP_LN_FWD(T, 3); else SP_LN_FWD(T, 4); }
+    if (dtype == SP_F32) SP_LN_FWD_T(float) else SP_LN_FWD_T(__hip_bfloat16)
+#undef SP_LN_FWD_T
+#undef SP_LN_FWD
     return check_launch("ln_fwd_kernel");
 }
 
@@ -205,12 +263,13 @@ extern "C" int sp_layernorm_bwd(const void* gy, const void* x, const float* mean
     if (blocks > 512) blocks = 512;
     const size_t lds = (size_t)8 * N * sizeof(float);
     hipStream_t s = (hipStream_t)stream;
-    if (dtype == SP_F32)
-        hipLaunchKernelGGL((ln_bwd_kernel<float>), dim3((int)blocks), dim3(256), lds, s, (const float*)gy,
-                           (const float*)x, mean, rstd, gamma, (const float*)gres, M, N, (float*)gx, dgamma, dbeta);
-    else
-        hipLaunchKernelGGL((ln_bwd_kernel<__hip_bfloat16>), dim3((int)blocks), dim3(256), lds, s,
-                           (const __hip_bfloat16*)gy, (const __hip_bfloat16*)x, mean, rstd, gamma,
-                           (const __hip_bfloat16*)gres, M, N, (__hip_bfloat16*)gx, dgamma, dbeta);
+    const int nch = (N + 511) / 512;
+#define SP_LN_BWD(T, NCH) hipLaunchKernelGGL((ln_bwd_kernel<T, NCH>), dim3((int)blocks), dim3(256), lds, s, (const T*)gy, \
+                                             (const T*)x, mean, rstd, gamma, (const T*)gres, M, N, (T*)gx, dgamma, dbeta)
+#define SP_LN_BWD_T(T) { if (nch == 1) SP_LN_BWD(T, 1); else if (nch == 2) SP_LN_BWD(T, 2); \
+                         else if (nch == 3) SP_LN_BWD(T, 3); else SP_LN_BWD(T, 4); }
+    if (dtype == SP_F32) SP_LN_BWD_T(float) else SP_LN_BWD_T(__hip_bfloat16)
+#undef SP_LN_BWD_T
+#undef SP_LN_BWD
     return check_launch("ln_bwd_kernel");
 }

@@ -411,6 +411,366 @@ __global__ __launch_bounds__(192) void sru_bwd_ring_kernel(
     atomicAdd(&gbias[D2 + cd], gbr);
 }
 
+// ---------------------------------------------------------------------------------------------
+// Role-split forward (bf16, the production path): one workgroup = 64 columns and three waves.
+//   loader  LDS-DMA only: one global_load_lds_dwordx4 brings TWO time steps of the four streams
+//           (u0 u1 u2 x', 4 x 128 B each) into the ring.
+//   chain   the serial part and nothing else: f = sigmoid(u1 + v_f c' + b_f), c = u0 + (c' - u0) f
+//           (fma, exp, add, rcp, sub, fma per step); c goes to an LDS ring.
+//   output  one chunk behind: r = sigmoid(u2 + v_r c' + b_r), h = (c m - x') r + x' -- independent
+//           across steps -- then stores the chunk transposed through LDS: 16 bytes per lane
+//           (1 store of h and 2 of c per 8 steps instead of 16 narrow ones).
+// The ring kernels above keep both parts in one wave, which is issue-bound at ~40 instructions per
+// step with only two of a CU's four SIMDs occupied; here the chain wave carries ~13.
+// One raw s_barrier per chunk of 8 steps hands chunk j to the chain wave, chunk j-1 to the output
+// wave and slot (j-2) % R back to the loader.
+// ---------------------------------------------------------------------------------------------
+template <int K>
+__global__ __launch_bounds__(192) void sru_fwd_split_kernel(
+    const __hip_bfloat16* __restrict__ U, const __hip_bfloat16* __restrict__ xres,
+    const float* __restrict__ wc, const float* __restrict__ bias, const float* __restrict__ mask,
+    int Tn, int B, int d, __hip_bfloat16* __restrict__ h, float* __restrict__ cst) {
+    constexpr int CH = 8, R = 14, ROW = 512, R2 = 4;   // (R-2) chunks = 48 DMA ops = 48 KB in flight per workgroup
+    __shared__ __attribute__((aligned(16))) unsigned char ring[R * CH * ROW];   // 56 KB
+    __shared__ __attribute__((aligned(16))) float cring[R2][CH][64];            // 8 KB
+    __shared__ __attribute__((aligned(16))) unsigned short htile[CH][64];       // 1 KB
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int D2 = 2 * d;
+    const int col0 = blockIdx.x * 64;
+    const int b = col0 / D2, cd0 = col0 - b * D2, dir = cd0 / d;
+    const int nch = (Tn + CH - 1) / CH;
+    const int64_t ustep = (int64_t)B * K * D2, hstep = (int64_t)B * D2;
+
+    if (wave == 0) {
+        // ---- loader: lane = (step parity, stream, 16-byte piece) ----
+        const int sp = lane >> 5, stream = (lane >> 3) & 3, c8 = lane & 7;
+        const __hip_bfloat16* base;
+        int64_t step;
+        if (K == 4 || stream < 3) {
+            base = U + (int64_t)b * K * D2 + (int64_t)stream * D2 + cd0 + c8 * 8;
+            step = ustep;
+        } else {
+            base = xres + (int64_t)b * D2 + cd0 + c8 * 8;
+            step = hstep;
+        }
+        auto issue = [&](int c) {
+#pragma unroll
+            for (int s2 = 0; s2 < CH / 2; ++s2) {
+                const int i = min(c * CH + 2 * s2 + sp, Tn - 1);   // past the end: clamped re-loads
+                const int64_t t = dir ? Tn - 1 - i : i;
+                __builtin_amdgcn_global_load_lds((gptr_t)(base + t * step),
+                                                 (lptr_t)(ring + (((c % R) * CH) + 2 * s2) * ROW), 16, 0, 0);
+            }
+        };
+        for (int c = 0; c < R - 2; ++c) issue(c);
+        for (int j = 0; j <= nch; ++j) {
+            asm volatile("s_waitcnt vmcnt(%0)" ::"n"((R - 3) * (CH / 2)) : "memory");   // chunk j landed
+            __builtin_amdgcn_s_barrier();
+            issue(j + R - 2);   // into the slot the output wave released at this barrier
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // drain before the LDS is released
+        return;
+    }
+    const int cd = cd0 + lane;
+    if (wave == 1) {
+        // ---- chain ----
+        const float nvf = -kL2e * wc[cd], nbf = -kL2e * bias[cd];
+        float c = 0.f;
+        for (int j = 0; j <= nch; ++j) {
+            __builtin_amdgcn_s_barrier();
+            asm volatile("" ::: "memory");
+            if (j < nch) {
+                const unsigned char* slot = ring + ((j % R) * CH) * ROW + lane * 2;
+                float v0[CH], a1[CH];
+#pragma unroll
+                for (int s = 0; s < CH; ++s) {
+                    v0[s] = lds_bf16(slot + s * ROW);
+                    a1[s] = fmaf(-kL2e, lds_bf16(slot + s * ROW + 128), nbf);
+                }
+#pragma unroll
+                for (int s = 0; s < CH; ++s) {
+                    const float f = sigmoid_neg2(fmaf(nvf, c, a1[s]));
+                    c = fmaf(c - v0[s], f, v0[s]);
+                    cring[j % R2][s][lane] = c;
+                }
+            }
+        }
+        return;
+    }
+    // ---- output ----
+    const float nvr = -kL2e * wc[D2 + cd], nbr = -kL2e * bias[D2 + cd];
+    const float m = mask ? mask[(int64_t)b * D2 + cd] : 1.f;
+    __hip_bfloat16* hb = h + (int64_t)b * D2 + cd0;
+    float* cb = cst + (int64_t)b * D2 + cd0;
+    float cprev = 0.f;
+    for (int j = 0; j <= nch; ++j) {
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+        if (j >= 1) {
+            const int cj = j - 1;
+            const unsigned char* slot = ring + ((cj % R) * CH) * ROW + lane * 2;
+            float a2[CH], x[CH], cc[CH];
+#pragma unroll
+            for (int s = 0; s < CH; ++s) {
+                a2[s] = fmaf(-kL2e, lds_bf16(slot + s * ROW + 256), nbr);
+                x[s] = lds_bf16(slot + s * ROW + 384);
+                cc[s] = cring[cj % R2][s][lane];
+            }
+#pragma unroll
+            for (int s = 0; s < CH; ++s) {
+                const float r = sigmoid_neg2(fmaf(nvr, cprev, a2[s]));
+                const float hv = fmaf(fmaf(cc[s], m, -x[s]), r, x[s]);
+                htile[s][lane] = __builtin_bit_cast(unsigned short, __float2bfloat16(hv));
+                cprev = cc[s];
+            }
+            __builtin_amdgcn_wave_barrier();
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            {   // h: lane = (step, 8-column piece), 16 bytes
+                const int s = lane >> 3, p8 = lane & 7;
+                const int i = cj * CH + s;
+                if (i < Tn) {
+                    const int64_t t = dir ? Tn - 1 - i : i;
+                    *reinterpret_cast<uint4*>(hb + t * hstep + p8 * 8) = *reinterpret_cast<const uint4*>(&htile[s][p8 * 8]);
+                }
+            }
+#pragma unroll
+            for (int hf = 0; hf < 2; ++hf) {   // c: lane = (step, 4-column piece), 16 bytes
+                const int s = hf * 4 + (lane >> 4), p4 = lane & 15;
+                const int i = cj * CH + s;
+                if (i < Tn) {
+                    const int64_t t = dir ? Tn - 1 - i : i;
+                    *reinterpret_cast<float4*>(cb + t * hstep + p4 * 4) =
+                        *reinterpret_cast<const float4*>(&cring[cj % R2][s][p4 * 4]);
+                }
+            }
+            __builtin_amdgcn_wave_barrier();
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// Role-split backward (bf16).  With c' saved, everything except the cell-state gradient is
+// independent across time; that gradient obeys gc' = (gc + G) A + Bv with
+//   f, r as in the forward,  kappa = (c' - u0) f (1 - f),  A = f + kappa v_f,
+//   dr = g (c m - x') r (1 - r),  G = g r m,  Bv = dr v_r,
+// so the serial chain is an add and an fma per step.  One workgroup = 64 columns, four waves,
+// chunks of 4 steps, one raw s_barrier per chunk; in interval j
+//   loader  refills the ring slot of chunk j-2 with chunk j+R-2 (one LDS-DMA per step: u0 u1 u2 x'
+//           gh c', 896 B);
+//   f-side  chunk j:   f, 1-f, kappa, kappa c', A, q = c m - x'  -> LDS;  stores g0/df of chunk j-3;
+//   r-side  chunk j-1: r, dr, gx, G, Bv (q from the f-side) -> LDS; stores dr/gx; sums for v_r, b_r;
+//   chain   chunk j-2: gct = gc + G, gc = gct A + Bv, g0 = gct (1-f), df = gct kappa -> LDS tiles;
+//           sums for v_f, b_f.
+// Stores leave transposed through LDS: 16 bytes per lane, one vector-memory op per wave and chunk.
+// ---------------------------------------------------------------------------------------------
+template <int K>
+__global__ __launch_bounds__(256) void sru_bwd_split_kernel(
+    const __hip_bfloat16* __restrict__ U, const __hip_bfloat16* __restrict__ xres,
+    const float* __restrict__ wc, const float* __restrict__ bias, const float* __restrict__ mask,
+    const float* __restrict__ cst, const __hip_bfloat16* __restrict__ gh, int Tn, int B, int d,
+    __hip_bfloat16* __restrict__ gU, __hip_bfloat16* __restrict__ gxres, float* __restrict__ gwc,
+    float* __restrict__ gbias) {
+    constexpr int CH = 4, R = 12, ROW = 1024;   // (R-2) chunks = 40 DMA ops = 35 KB in flight per workgroup
+    __shared__ __attribute__((aligned(16))) unsigned char ring[R * CH * ROW];            // 48 KB
+    __shared__ float sq[2][CH][64];                                                       // f-side -> r-side
+    __shared__ float sA[3][CH][64], sOmf[3][CH][64], sKap[3][CH][64], sKcp[3][CH][64];    // f-side -> chain
+    __shared__ float sG[2][CH][64], sBv[2][CH][64];                                       // r-side -> chain
+    __shared__ __attribute__((aligned(16))) unsigned short tg[2][2][CH][64];              // chain -> f-side: g0 | df
+    __shared__ __attribute__((aligned(16))) unsigned short tr[2][CH][64];                 // r-side: dr | gx
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int D2 = 2 * d;
+    const int col0 = blockIdx.x * 64;
+    const int b = col0 / D2, cd0 = col0 - b * D2, dir = cd0 / d;
+    const int nch = (Tn + CH - 1) / CH;
+    const int nint = nch + 3;   // barriers every wave executes
+    const int64_t ustep = (int64_t)B * K * D2, hstep = (int64_t)B * D2;
+    // time index of backward step jr (jr = 0 is the last forward step)
+    auto t_of = [&](int jr) { const int i = Tn - 1 - jr; return (int64_t)(dir ? Tn - 1 - i : i); };
+
+    if (wave == 0) {
+        // ---- loader: lanes 0-31 (stream, piece) of U / x', 32-39 gh, 40-55 c' (f32), 56-63 idle ----
+        const char* base;
+        int64_t stepb;   // bytes per time step
+        if (lane < 32) {
+            const int stream = lane >> 3, c8 = lane & 7;
+            if (K == 4 || stream < 3) {
+                base = reinterpret_cast<const char*>(U + (int64_t)b * K * D2 + (int64_t)stream * D2 + cd0 + c8 * 8);
+                stepb = ustep * 2;
+            } else {
+                base = reinterpret_cast<const char*>(xres + (int64_t)b * D2 + cd0 + c8 * 8);
+                stepb = hstep * 2;
+            }
+        } else if (lane < 40) {
+            base = reinterpret_cast<const char*>(gh + (int64_t)b * D2 + cd0 + (lane - 32) * 8);
+            stepb = hstep * 2;
+        } else {
+            base = reinterpret_cast<const char*>(cst + (int64_t)b * D2 + cd0 + (min(lane, 55) - 40) * 4);
+            stepb = hstep * 4;
+        }
+        const bool is_cp = lane >= 40;
+        auto issue = [&](int c) {
+#pragma unroll
+            for (int s = 0; s < CH; ++s) {
+                const int jr = min(c * CH + s, Tn - 1);    // past the end: clamped re-loads
+                const int i = Tn - 1 - jr;
+                const int il = is_cp ? max(i - 1, 0) : i;   // c' = cell state of forward step i-1
+                const int64_t t = dir ? Tn - 1 - il : il;
+                if (lane < 56)
+                    __builtin_amdgcn_global_load_lds((gptr_t)(base + t * stepb),
+                                                     (lptr_t)(ring + (((c % R) * CH) + s) * ROW), 16, 0, 0);
+            }
+        };
+        for (int c = 0; c < R - 2; ++c) issue(c);
+        for (int j = 0; j < nint; ++j) {
+            asm volatile("s_waitcnt vmcnt(%0)" ::"n"((R - 3) * CH) : "memory");   // chunk j landed
+            __builtin_amdgcn_s_barrier();
+            issue(j + R - 2);   // slot of chunk j-2: last read by the r-side in interval j-1
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        return;
+    }
+    const int cd = cd0 + lane;
+    if (wave == 1) {
+        // ---- f-side ----
+        const float vf = wc[cd];
+        const float nvf = -kL2e * vf, nbf = -kL2e * bias[cd];
+        const float m = mask ? mask[(int64_t)b * D2 + cd] : 1.f;
+        __hip_bfloat16* gUb = gU + (int64_t)b * K * D2 + cd0;
+        for (int j = 0; j < nint; ++j) {
+            __builtin_amdgcn_s_barrier();
+            asm volatile("" ::: "memory");
+            if (j < nch) {
+                const unsigned char* slot = ring + ((j % R) * CH) * ROW;
+                float u0[CH], a1[CH], x[CH], cp[CH];
+#pragma unroll
+                for (int s = 0; s < CH; ++s) {
+                    const unsigned char* row = slot + s * ROW;
+                    u0[s] = lds_bf16(row + lane * 2);
+                    a1[s] = fmaf(-kL2e, lds_bf16(row + 128 + lane * 2), nbf);
+                    x[s] = lds_bf16(row + 384 + lane * 2);
+                    cp[s] = *reinterpret_cast<const float*>(row + 640 + lane * 4);
+                    if (j * CH + s >= Tn - 1) cp[s] = 0.f;   // forward step 0 has no predecessor
+                }
+#pragma unroll
+                for (int s = 0; s < CH; ++s) {
+                    const float f = sigmoid_neg2(fmaf(nvf, cp[s], a1[s]));
+                    const float omf = 1.f - f;
+                    const float d0 = cp[s] - u0[s];
+                    const float kap = d0 * f * omf;
+                    sA[j % 3][s][lane] = fmaf(kap, vf, f);
+                    sOmf[j % 3][s][lane] = omf;
+                    sKap[j % 3][s][lane] = kap;
+                    sKcp[j % 3][s][lane] = kap * cp[s];
+                    sq[j & 1][s][lane] = fmaf(fmaf(d0, f, u0[s]), m, -x[s]);
+                }
+            }
+            const int cs = j - 3;   // chunk whose g0/df tiles the chain wave finished in interval j-1
+            if (cs >= 0 && cs < nch) {
+                const int pl = lane >> 5, s = (lane >> 3) & 3, p8 = lane & 7;   // plane 0: g0, 1: df
+                const int jr = cs * CH + s;
+                if (jr < Tn)
+                    *reinterpret_cast<uint4*>(gUb + t_of(jr) * ustep + (int64_t)pl * D2 + p8 * 8) =
+                        *reinterpret_cast<const uint4*>(&tg[cs & 1][pl][s][p8 * 8]);
+            }
+        }
+        return;
+    }
+    if (wave == 2) {
+        // ---- r-side ----
+        const float vr = wc[D2 + cd];
+        const float nvr = -kL2e * vr, nbr = -kL2e * bias[D2 + cd];
+        const float m = mask ? mask[(int64_t)b * D2 + cd] : 1.f;
+        // lanes 0-31 store dr (plane 2 of gU), lanes 32-63 gx (gxres, or plane 3 when K == 4)
+        __hip_bfloat16* sbase;
+        int64_t sstep;
+        if (lane < 32 || K == 4) {
+            sbase = gU + (int64_t)b * K * D2 + (int64_t)(lane < 32 ? 2 : 3) * D2 + cd0;
+            sstep = ustep;
+        } else {
+            sbase = gxres + (int64_t)b * D2 + cd0;
+            sstep = hstep;
+        }
+        float gvr = 0.f, gbr = 0.f;
+        for (int j = 0; j < nint; ++j) {
+            __builtin_amdgcn_s_barrier();
+            asm volatile("" ::: "memory");
+            const int c = j - 1;
+            if (c >= 0 && c < nch) {
+                const unsigned char* slot = ring + ((c % R) * CH) * ROW;
+                float a2[CH], g[CH], cp[CH], q[CH];
+#pragma unroll
+                for (int s = 0; s < CH; ++s) {
+                    const unsigned char* row = slot + s * ROW;
+                    a2[s] = fmaf(-kL2e, lds_bf16(row + 256 + lane * 2), nbr);
+                    g[s] = lds_bf16(row + 512 + lane * 2);
+                    cp[s] = *reinterpret_cast<const float*>(row + 640 + lane * 4);
+                    if (c * CH + s >= Tn - 1) cp[s] = 0.f;
+                    q[s] = sq[c & 1][s][lane];
+                }
+#pragma unroll
+                for (int s = 0; s < CH; ++s) {
+                    const float r = sigmoid_neg2(fmaf(nvr, cp[s], a2[s]));
+                    const float omr = 1.f - r;
+                    const float gr = g[s] * q[s];
+                    const float dr = gr * r * omr;
+                    sG[c & 1][s][lane] = g[s] * r * m;
+                    sBv[c & 1][s][lane] = dr * vr;
+                    tr[0][s][lane] = __builtin_bit_cast(unsigned short, __float2bfloat16(dr));
+                    tr[1][s][lane] = __builtin_bit_cast(unsigned short, __float2bfloat16(g[s] * omr));
+                    const float drv = (c * CH + s < Tn) ? dr : 0.f;   // select, not a branch: the four steps interleave
+                    gvr = fmaf(drv, cp[s], gvr);
+                    gbr += drv;
+                }
+                __builtin_amdgcn_wave_barrier();
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                {
+                    const int pl = lane >> 5, s = (lane >> 3) & 3, p8 = lane & 7;
+                    const int jr = c * CH + s;
+                    if (jr < Tn)
+                        *reinterpret_cast<uint4*>(sbase + t_of(jr) * sstep + p8 * 8) =
+                            *reinterpret_cast<const uint4*>(&tr[pl][s][p8 * 8]);
+                }
+                __builtin_amdgcn_wave_barrier();
+            }
+        }
+        atomicAdd(&gwc[D2 + cd], gvr);
+        atomicAdd(&gbias[D2 + cd], gbr);
+        return;
+    }
+    // ---- chain ----
+    float gc = 0.f, gvf = 0.f, gbf = 0.f;
+    for (int j = 0; j < nint; ++j) {
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+        const int c = j - 2;
+        if (c >= 0 && c < nch) {
+            float G[CH], A[CH], Bv[CH], omf[CH], kap[CH], kcp[CH];
+#pragma unroll
+            for (int s = 0; s < CH; ++s) {
+                G[s] = sG[c & 1][s][lane];
+                Bv[s] = sBv[c & 1][s][lane];
+                A[s] = sA[c % 3][s][lane];
+                omf[s] = sOmf[c % 3][s][lane];
+                kap[s] = sKap[c % 3][s][lane];
+                kcp[s] = sKcp[c % 3][s][lane];
+            }
+#pragma unroll
+            for (int s = 0; s < CH; ++s) {
+                const float gct = gc + G[s];
+                gc = fmaf(gct, A[s], Bv[s]);
+                const float df = gct * kap[s];
+                tg[c & 1][0][s][lane] = __builtin_bit_cast(unsigned short, __float2bfloat16(gct * omf[s]));
+                tg[c & 1][1][s][lane] = __builtin_bit_cast(unsigned short, __float2bfloat16(df));
+                const float vs = (c * CH + s < Tn) ? 1.f : 0.f;   // select, not a branch
+                gvf = fmaf(gct * vs, kcp[s], gvf);
+                gbf = fmaf(df, vs, gbf);
+            }
+        }
+    }
+    atomicAdd(&gwc[cd], gvf);
+    atomicAdd(&gbias[cd], gbf);
+}
+
 template <typename T>
 static int sru_fwd_t(const void* U, const void* xres, const float* wc, const float* bias,
                      const float* mask, int Tn, int B, int d, int k, void* h, float* c, hipStream_t s) {
@@ -460,16 +820,16 @@ extern "C" int sp_sru_fwd(const void* U, const void* xres, const float* wc, cons
     SP_CHECK_ARG(U && wc && bias && h && c && (k == 4 || xres), "sp_sru_fwd: null pointer");
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
     if (dtype == SP_F32) return sru_fwd_t<float>(U, xres, wc, bias, mask, T, B, d, k, h, c, s);
-    if (d % 128 == 0) {  // loader-ring path
+    {   // role-split path (any d % 64 == 0)
         typedef __hip_bfloat16 bf;
-        const int blocks = B * 2 * d / 128;
+        const int blocks = B * 2 * d / 64;
         if (k == 3)
-            hipLaunchKernelGGL((sru_fwd_ring_kernel<3>), dim3(blocks), dim3(192), 0, s, (const bf*)U, (const bf*)xres,
+            hipLaunchKernelGGL((sru_fwd_split_kernel<3>), dim3(blocks), dim3(192), 0, s, (const bf*)U, (const bf*)xres,
                                wc, bias, mask, T, B, d, (bf*)h, c);
         else
-            hipLaunchKernelGGL((sru_fwd_ring_kernel<4>), dim3(blocks), dim3(192), 0, s, (const bf*)U, (const bf*)xres,
+            hipLaunchKernelGGL((sru_fwd_split_kernel<4>), dim3(blocks), dim3(192), 0, s, (const bf*)U, (const bf*)xres,
                                wc, bias, mask, T, B, d, (bf*)h, c);
-        return check_launch("sru_fwd_ring_kernel");
+        return check_launch("sru_fwd_split_kernel");
     }
     return sru_fwd_t<__hip_bfloat16>(U, xres, wc, bias, mask, T, B, d, k, h, c, s);
 }
@@ -487,16 +847,16 @@ extern "C" int sp_sru_bwd(const void* U, const void* xres, const float* wc, cons
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
     if (dtype == SP_F32)
         return sru_bwd_t<float>(U, xres, wc, bias, mask, c, gh, T, B, d, k, gU, gxres, gwc, gbias, s);
-    if (d % 128 == 0) {  // loader-ring path
+    {   // role-split path (any d % 64 == 0)
         typedef __hip_bfloat16 bf;
-        const int blocks = B * 2 * d / 128;
+        const int blocks = B * 2 * d / 64;
         if (k == 3)
-            hipLaunchKernelGGL((sru_bwd_ring_kernel<3>), dim3(blocks), dim3(192), 0, s, (const bf*)U, (const bf*)xres,
+            hipLaunchKernelGGL((sru_bwd_split_kernel<3>), dim3(blocks), dim3(256), 0, s, (const bf*)U, (const bf*)xres,
                                wc, bias, mask, c, (const bf*)gh, T, B, d, (bf*)gU, (bf*)gxres, gwc, gbias);
         else
-            hipLaunchKernelGGL((sru_bwd_ring_kernel<4>), dim3(blocks), dim3(192), 0, s, (const bf*)U, (const bf*)xres,
+            hipLaunchKernelGGL((sru_bwd_split_kernel<4>), dim3(blocks), dim3(256), 0, s, (const bf*)U, (const bf*)xres,
                                wc, bias, mask, c, (const bf*)gh, T, B, d, (bf*)gU, (bf*)gxres, gwc, gbias);
-        return check_launch("sru_bwd_ring_kernel");
+        return check_launch("sru_bwd_split_kernel");
     }
     return sru_bwd_t<__hip_bfloat16>(U, xres, wc, bias, mask, c, gh, T, B, d, k, gU, gxres, gwc, gbias, s);
 }

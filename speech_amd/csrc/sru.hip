@@ -430,8 +430,8 @@ __global__ __launch_bounds__(192) void sru_fwd_split_kernel(
     const __hip_bfloat16* __restrict__ U, const __hip_bfloat16* __restrict__ xres,
     const float* __restrict__ wc, const float* __restrict__ bias, const float* __restrict__ mask,
     int Tn, int B, int d, __hip_bfloat16* __restrict__ h, float* __restrict__ cst) {
-    constexpr int CH = 8, R = 14, ROW = 512, R2 = 4;   // (R-2) chunks = 48 DMA ops = 48 KB in flight per workgroup
-    __shared__ __attribute__((aligned(16))) unsigned char ring[R * CH * ROW];   // 56 KB
+    constexpr int CH = 8, R = 8, ROW = 512, R2 = 4;   // (R-2) chunks = 24 DMA ops = 24 KB in flight per workgroup
+    __shared__ __attribute__((aligned(16))) unsigned char ring[R * CH * ROW];   // 32 KB
     __shared__ __attribute__((aligned(16))) float cring[R2][CH][64];            // 8 KB
     __shared__ __attribute__((aligned(16))) unsigned short htile[CH][64];       // 1 KB
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
@@ -577,7 +577,11 @@ __global__ __launch_bounds__(256) void sru_bwd_split_kernel(
     __shared__ float sG[2][CH][64], sBv[2][CH][64];                                       // r-side -> chain
     __shared__ __attribute__((aligned(16))) unsigned short tg[2][2][CH][64];              // chain -> f-side: g0 | df
     __shared__ __attribute__((aligned(16))) unsigned short tr[2][CH][64];                 // r-side: dr | gx
-    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    // Two workgroups share a CU and wave w of each lands on SIMD w % 4: rotating the roles of every
+    // other workgroup by two pairs the heavy r-side with the loader and the f-side with the chain
+    // on each SIMD instead of stacking the two r-sides.
+    const int rot = ((blockIdx.x ^ (blockIdx.x >> 8)) & 1) * 2;
+    const int wave = ((threadIdx.x >> 6) + rot) & 3, lane = threadIdx.x & 63;
     const int D2 = 2 * d;
     const int col0 = blockIdx.x * 64;
     const int b = col0 / D2, cd0 = col0 - b * D2, dir = cd0 / d;

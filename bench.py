@@ -77,56 +77,64 @@ def time_kernel(fn, iters):
 
 
 def kernel_rooflines(args, model, wav, offs, labels, lens, Lmax, V, iters):
-    """Per-kernel HBM / MFMA roofline lines for the hand-written kernels, measured live."""
-    from speech_amd import ops
+    """Per-kernel HBM roofline lines for the hand-written north-star kernels, measured live: the
+    C-ABI entry points are called directly on pre-allocated buffers (no host-side checks, copies or
+    allocations inside the timed loop), HIP events on the stream the kernels are launched on."""
+    from speech_amd import _lib, ops
+    from speech_amd._lib import check, lib, ptr, stream_ptr
+    L = lib()
     dev = wav.device
     B, N = args.batch, int(args.seconds * 16000)
     out = {}
+
+    def line(name, by, ms, launches):
+        out[name] = {"bound": "hbm", "achieved": by / ms / 1e6, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                     "frac": by / ms / 1e6 / HBM_PEAK_GBS, "ms": ms, "algorithmic_bytes": by,
+                     "launches_per_step": launches}
+
     # frontend: 4*sum(N) + 4*80*B*Tmax bytes (SURVEY.md 8d)
     masks = torch.tensor([[10, 10, 100, 30]] * B, dtype=torch.int32, device=dev)
     T = 1 + N // 160
     spec_buf = torch.empty((B, 1, 80, T), dtype=torch.float32, device=dev)
-    ms = time_kernel(lambda: ops.melspec(wav, offs, masks=masks, out=spec_buf), iters)
-    by = 4.0 * B * N + 4.0 * 80 * B * T
-    out["melspec_kernel"] = {"bound": "hbm", "achieved": by / ms / 1e6, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                             "frac": by / ms / 1e6 / HBM_PEAK_GBS, "ms": ms, "algorithmic_bytes": by,
-                             "launches_per_step": 1}
-    # CTC: scores read + grad write + lattice write/read (2*4*sum T'*S_b)
+    plan = ops.default_plan(dev)
+    st = stream_ptr()
+    ms = time_kernel(lambda: check(L.sp_melspec_fwd(ptr(wav), ptr(offs), B, T, ptr(plan.buf), ptr(masks), 0,
+                                                    ptr(spec_buf), st), "mel"), iters)
+    line("melspec_kernel", 4.0 * B * N + 4.0 * 80 * B * T, ms, 1)
+    # CTC: scores read + grad write + f64 alpha/beta lattice write and read (2*8*sum T'*S_b)
     Tp = (T - 1) // 2 + 1
     logits = torch.randn(B, Tp, V, device=dev) * 3
     il = torch.full((B,), Tp, dtype=torch.int32, device=dev)
-    ms = time_kernel(lambda: ops.ctc_fwd_bwd(logits, labels, il, lens, max_label_len=Lmax), iters)
+    nll = torch.empty(B, device=dev); loss = torch.empty(1, device=dev); grad = torch.empty_like(logits)
+    ws = torch.empty(L.sp_ctc_workspace_bytes(Tp, B, V, Lmax), dtype=torch.uint8, device=dev)
+    ms = time_kernel(lambda: check(L.sp_ctc_fwd_bwd(ptr(logits), logits.stride(1), logits.stride(0), ptr(labels),
+                                                    labels.stride(0), ptr(il), ptr(lens), Tp, B, V, 0, Lmax, 1.0,
+                                                    ptr(nll), ptr(loss), ptr(grad), ptr(ws), ws.numel(), st), "ctc"), iters)
     S = (2 * lens.float() + 1).sum().item()
-    by = 2 * 4.0 * Tp * B * V + 2 * 4.0 * Tp * S
-    out["ctc_fwd_bwd(3 kernels)"] = {"bound": "hbm", "achieved": by / ms / 1e6, "peak": HBM_PEAK_GBS,
-                                     "unit": "GB/s", "frac": by / ms / 1e6 / HBM_PEAK_GBS, "ms": ms,
-                                     "algorithmic_bytes": by, "launches_per_step": 1}
+    line("ctc_fwd_bwd(3 kernels)", 2 * 4.0 * Tp * B * V + 2 * 8.0 * Tp * S, ms, 1)
     # decode: scores read + ids write
-    ms = time_kernel(lambda: ops.greedy_decode_ids(logits), iters)
-    by = 4.0 * B * Tp * V + 4.0 * B * Tp
-    out["greedy_decode_kernel"] = {"bound": "hbm", "achieved": by / ms / 1e6, "peak": HBM_PEAK_GBS,
-                                   "unit": "GB/s", "frac": by / ms / 1e6 / HBM_PEAK_GBS, "ms": ms,
-                                   "algorithmic_bytes": by, "launches_per_step": 0}   # eval path only
-    # SRU recurrence forward, one k=3 layer: U + xres read, h + c written
+    ids = torch.empty((B, Tp), dtype=torch.int32, device=dev); nids = torch.empty(B, dtype=torch.int32, device=dev)
+    ms = time_kernel(lambda: check(L.sp_greedy_decode(ptr(logits), _lib.dtype_code(logits), B, Tp, V, 0, None, ptr(ids),
+                                                      ptr(nids), st), "decode"), iters)
+    line("greedy_decode(2 kernels)", 4.0 * B * Tp * V + 4.0 * B * Tp, ms, 0)   # eval path only
+    # SRU recurrence, one k=3 layer: forward reads U + x', writes h + c; backward reads U, x', c, gh, writes gU, gx
     d = 512
     e = 2 if args.dtype == "bf16" else 4
     adt = torch.bfloat16 if args.dtype == "bf16" else torch.float32
+    dc = _lib.dtype_code(torch.empty(0, dtype=adt))
     U = torch.randn(Tp, B, 3, 2, d, device=dev).to(adt)
     xr = torch.randn(Tp, B, 2 * d, device=dev).to(adt)
     wc = torch.randn(4 * d, device=dev) * 0.5
     bias = torch.zeros(4 * d, device=dev)
-    ms = time_kernel(lambda: ops.sru_fwd(U, xr, wc, bias, None, Tp, B, d, 3), iters)
-    by = Tp * B * 2 * d * (3 * e + e + e + 4.0)
-    out["sru_fwd_kernel"] = {"bound": "hbm", "achieved": by / ms / 1e6, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                             "frac": by / ms / 1e6 / HBM_PEAK_GBS, "ms": ms, "algorithmic_bytes": by,
-                             "launches_per_step": 10}
-    h, c = ops.sru_fwd(U, xr, wc, bias, None, Tp, B, d, 3)
-    gh = torch.randn_like(h)
-    ms = time_kernel(lambda: ops.sru_bwd(U, xr, wc, bias, None, c, gh, Tp, B, d, 3), iters)
-    by = Tp * B * 2 * d * (3 * e + e + e + 4.0 + 3 * e + e)
-    out["sru_bwd_kernel"] = {"bound": "hbm", "achieved": by / ms / 1e6, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                             "frac": by / ms / 1e6 / HBM_PEAK_GBS, "ms": ms, "algorithmic_bytes": by,
-                             "launches_per_step": 10}
+    h = torch.empty(Tp, B, 2 * d, device=dev, dtype=adt); c = torch.empty(Tp, B, 2 * d, device=dev)
+    ms = time_kernel(lambda: check(L.sp_sru_fwd(ptr(U), ptr(xr), ptr(wc), ptr(bias), None, Tp, B, d, 3, dc, ptr(h), ptr(c), st),
+                                   "sru_fwd"), iters)
+    line("sru_fwd_kernel", Tp * B * 2 * d * (3 * e + e + e + 4.0), ms, 10)
+    gh = torch.randn_like(h); gU = torch.empty_like(U); gx = torch.empty_like(xr)
+    gwc = torch.zeros(4 * d, device=dev); gb = torch.zeros(4 * d, device=dev)
+    ms = time_kernel(lambda: check(L.sp_sru_bwd(ptr(U), ptr(xr), ptr(wc), ptr(bias), None, ptr(c), ptr(gh), Tp, B, d, 3, dc,
+                                                ptr(gU), ptr(gx), ptr(gwc), ptr(gb), st), "sru_bwd"), iters)
+    line("sru_bwd_kernel", Tp * B * 2 * d * (3 * e + e + e + 4.0 + 3 * e + e), ms, 10)
     return out
 
 

@@ -105,7 +105,7 @@ class _ConvStackFn(torch.autograd.Function):
         grads = []
         with torch.cuda.device(dev):
             s = stream_ptr()
-            ws = torch.empty(15 * 32 * 32, dtype=torch.float32, device=dev)
+            ws = torch.empty(8 * 15 * 32 * 32, dtype=torch.float32, device=dev)
             for i in range(nblk - 1, -1, -1):
                 x, y1, y2, z, zs, coef1, save1, save2, c1w, c2w, b1w, b2w = ctx.saved[i]
                 z32 = lambda: torch.zeros(32, dtype=torch.float32, device=dev)  # noqa: E731

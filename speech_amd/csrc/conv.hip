@@ -234,12 +234,30 @@ __global__ __launch_bounds__(256, 2) void conv3x5_kernel(
 // ---------------------------------------------------------------------------------------------
 constexpr int kWR = 72;  // padded row (positions) of the transposed LDS images, 144 bytes
 
+// 16 bytes at bf16-element offset E (0..4) of a 32-byte window held as two uint4
+template <int E>
+__device__ __forceinline__ uint4 window16(const uint4& lo, const uint4& hi) {
+    const uint32_t w[8] = {lo.x, lo.y, lo.z, lo.w, hi.x, hi.y, hi.z, hi.w};
+    uint4 o;
+    if (E % 2 == 0) {
+        o.x = w[E / 2]; o.y = w[E / 2 + 1]; o.z = w[E / 2 + 2]; o.w = w[E / 2 + 3];
+    } else {
+        o.x = __builtin_amdgcn_alignbit(w[E / 2 + 1], w[E / 2], 16);
+        o.y = __builtin_amdgcn_alignbit(w[E / 2 + 2], w[E / 2 + 1], 16);
+        o.z = __builtin_amdgcn_alignbit(w[E / 2 + 3], w[E / 2 + 2], 16);
+        o.w = __builtin_amdgcn_alignbit(w[E / 2 + 4], w[E / 2 + 3], 16);
+    }
+    return o;
+}
+
 template <int A_MODE>
 __global__ __launch_bounds__(320) void conv3x5_wgrad_kernel(
     const __hip_bfloat16* __restrict__ asrc, const float* __restrict__ acoef,
     const __hip_bfloat16* __restrict__ g, const __hip_bfloat16* __restrict__ y,
     const float* __restrict__ gcoef, int B, int F, int T, int fsplit, float* __restrict__ gwp) {
-    __shared__ __attribute__((aligned(16))) __hip_bfloat16 gys[5 * 32 * kWR];
+    // dy row: ONE transposed copy [co][68 positions, origin t0-2]; the five kw taps read the same
+    // aligned 32-byte windows and shift them in registers (v_alignbit), instead of five shifted copies
+    __shared__ __attribute__((aligned(16))) __hip_bfloat16 gys[32 * kWR];
     __shared__ __attribute__((aligned(16))) __hip_bfloat16 aring[3 * 32 * kWR];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int r = lane & 31, h = lane >> 5;
@@ -250,57 +268,59 @@ __global__ __launch_bounds__(320) void conv3x5_wgrad_kernel(
     const int64_t img = (int64_t)b * F * T;
     const int ch4 = tid & 3;
 
-    float ga[8], gb[8], gd[8], a0[8], a1[8];
-#pragma unroll
-    for (int j = 0; j < 8; ++j) {
-        ga[j] = gcoef[ch4 * 8 + j];
-        gb[j] = gcoef[32 + ch4 * 8 + j];
-        gd[j] = gcoef[64 + ch4 * 8 + j];
-        a0[j] = (A_MODE == IN_BNRELU) ? acoef[ch4 * 8 + j] : 1.f;
-        a1[j] = (A_MODE == IN_BNRELU) ? acoef[32 + ch4 * 8 + j] : 0.f;
-    }
+    // per-channel coefficients live in LDS (40 VGPRs otherwise: the kernel must stay under 128 to keep
+    // four waves per SIMD, which is what hides the per-row HBM latency)
+    __shared__ __attribute__((aligned(16))) float scoef[5][32];   // ga gb gd a0 a1
+    if (tid < 96) scoef[tid >> 5][tid & 31] = gcoef[tid];
+    else if (tid < 160) scoef[3 + ((tid - 96) >> 5)][tid & 31] = (A_MODE == IN_BNRELU) ? acoef[tid - 96] : ((tid < 128) ? 1.f : 0.f);
+    __syncthreads();
+    const float* ga = scoef[0] + ch4 * 8;
+    const float* gb = scoef[1] + ch4 * 8;
+    const float* gd = scoef[2] + ch4 * 8;
+    const float* a0 = scoef[3] + ch4 * 8;
+    const float* a1 = scoef[4] + ch4 * 8;
 
-    auto stage_a = [&](int frow) {  // activation row frow -> ring slot (frow + 3) % 3, [ci][pos]
+    // global -> registers (issued one f-row ahead) and registers -> LDS (transposed) are split so
+    // that a row's HBM latency hides behind the previous row's MFMAs
+    struct RowRegs { uint4 a, g, y; bool aok, gok; };
+    auto load_row = [&](int frow_a, int frow_g, RowRegs& rr) {
+        rr.a = rr.g = rr.y = make_uint4(0, 0, 0, 0);
+        const int pos = tid >> 2, ta = t0 + pos;
+        rr.aok = tid < 256 && frow_a >= 0 && frow_a < F && ta < T;
+        if (rr.aok) rr.a = *reinterpret_cast<const uint4*>(asrc + (img + (int64_t)frow_a * T + ta) * kC + ch4 * 8);
+        const int tg = t0 - 2 + pos;
+        rr.gok = tid < 272 && frow_g >= 0 && frow_g < F && tg >= 0 && tg < T;
+        if (rr.gok) {
+            const int64_t off = (img + (int64_t)frow_g * T + tg) * kC + ch4 * 8;
+            rr.g = *reinterpret_cast<const uint4*>(g + off);
+            rr.y = *reinterpret_cast<const uint4*>(y + off);
+        }
+    };
+    auto store_a = [&](int frow, const RowRegs& rr) {   // activation row -> ring slot (frow + 3) % 3, [ci][pos]
         if (tid < 256) {
-            const int pos = tid >> 2, t = t0 + pos;
-            float x[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-            if (frow >= 0 && frow < F && t < T) {
-                const uint4 v = *reinterpret_cast<const uint4*>(asrc + (img + (int64_t)frow * T + t) * kC + ch4 * 8);
-                unpack8(v, x);
-                if (A_MODE == IN_BNRELU) {
+            const int pos = tid >> 2;
+            float x[8];
+            unpack8(rr.a, x);
+            if (A_MODE == IN_BNRELU) {
 #pragma unroll
-                    for (int j = 0; j < 8; ++j) x[j] = fmaxf(0.f, a0[j] * x[j] + a1[j]);
-                }
+                for (int j = 0; j < 8; ++j) x[j] = rr.aok ? fmaxf(0.f, a0[j] * x[j] + a1[j]) : 0.f;
             }
             __hip_bfloat16* dst = aring + ((frow + 3) % 3) * 32 * kWR + (ch4 * 8) * kWR + pos;
 #pragma unroll
             for (int j = 0; j < 8; ++j) dst[j * kWR] = __float2bfloat16(x[j]);
         }
     };
-    auto stage_g = [&](int frow) {  // dy row (BN-backward affine applied) -> 5 shifted copies [co][pos]
+    auto store_g = [&](const RowRegs& rr) {   // dy row (BN-backward affine applied) -> [co][idx]
         if (tid < 272) {
-            const int idx = tid >> 2, t = t0 - 2 + idx;
-            float x[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-            if (t >= 0 && t < T) {
-                const int64_t off = (img + (int64_t)frow * T + t) * kC + ch4 * 8;
-                float yv[8];
-                unpack8(*reinterpret_cast<const uint4*>(g + off), x);
-                unpack8(*reinterpret_cast<const uint4*>(y + off), yv);
+            const int idx = tid >> 2;
+            float x[8], yv[8];
+            unpack8(rr.g, x);
+            unpack8(rr.y, yv);
 #pragma unroll
-                for (int j = 0; j < 8; ++j) x[j] = ga[j] * x[j] + gb[j] * yv[j] + gd[j];
-            }
-            __hip_bfloat16 xb[8];
+            for (int j = 0; j < 8; ++j) x[j] = rr.gok ? ga[j] * x[j] + gb[j] * yv[j] + gd[j] : 0.f;
+            __hip_bfloat16* dst = gys + (ch4 * 8) * kWR + idx;
 #pragma unroll
-            for (int j = 0; j < 8; ++j) xb[j] = __float2bfloat16(x[j]);
-#pragma unroll
-            for (int s = 0; s < 5; ++s) {
-                const int i = idx + s - 4;  // copy s holds dy[t0 + i - s + 2] at column i
-                if (i >= 0 && i < 64) {
-                    __hip_bfloat16* dst = gys + (s * 32 + ch4 * 8) * kWR + i;
-#pragma unroll
-                    for (int j = 0; j < 8; ++j) dst[j * kWR] = xb[j];
-                }
-            }
+            for (int j = 0; j < 8; ++j) dst[j * kWR] = __float2bfloat16(x[j]);
         }
     };
 
@@ -310,17 +330,40 @@ __global__ __launch_bounds__(320) void conv3x5_wgrad_kernel(
 #pragma unroll
         for (int q = 0; q < 16; ++q) acc[k][q] = 0.f;
 
-    stage_a(fa - 1);
-    stage_a(fa);
+    // rows are requested PF iterations ahead (an iteration is ~0.5 us of LDS + MFMA work, an HBM
+    // round trip 2+ us): q[0] is the row being stored now, q[PF-1] the one just requested
+    constexpr int PF = 1;
+    RowRegs q[PF];
+    {
+        RowRegs p0, p1;
+        load_row(fa - 1, -1, p0);
+        load_row(fa, -1, p1);
+        store_a(fa - 1, p0);
+        store_a(fa, p1);
+    }
+#pragma unroll
+    for (int i = 0; i < PF; ++i) load_row(fa + 1 + i, fa + i < fb ? fa + i : -1, q[i]);
     for (int f = fa; f < fb; ++f) {
-        stage_a(f + 1);
-        stage_g(f);
+        store_a(f + 1, q[0]);
+        store_g(q[0]);
+#pragma unroll
+        for (int i = 0; i + 1 < PF; ++i) q[i] = q[i + 1];
+        load_row(f + 1 + PF, f + PF < fb ? f + PF : -1, q[PF - 1]);
         __syncthreads();
-        const int kw = wave;
 #pragma unroll
         for (int ks = 0; ks < 4; ++ks) {
-            const bf16x8 A = __builtin_bit_cast(
-                bf16x8, *reinterpret_cast<const uint4*>(gys + (kw * 32 + r) * kWR + ks * 16 + 8 * h));
+            const uint4* wp = reinterpret_cast<const uint4*>(gys + r * kWR + ks * 16 + 8 * h);
+            const uint4 lo = wp[0], hi = wp[1];
+            // tap kw = wave reads dy at column offset 4 - kw of the window
+            uint4 av;
+            switch (wave) {
+                case 0: av = window16<4>(lo, hi); break;
+                case 1: av = window16<3>(lo, hi); break;
+                case 2: av = window16<2>(lo, hi); break;
+                case 3: av = window16<1>(lo, hi); break;
+                default: av = window16<0>(lo, hi); break;
+            }
+            const bf16x8 A = __builtin_bit_cast(bf16x8, av);
 #pragma unroll
             for (int kh = 0; kh < 3; ++kh) {
                 const int slot = (f + kh + 2) % 3;  // row f + kh - 1
@@ -331,14 +374,17 @@ __global__ __launch_bounds__(320) void conv3x5_wgrad_kernel(
         }
         __syncthreads();
     }
-    // D[row = co][col = ci]: lane = ci, registers = co 8g + 4h + i; gwp[tap][co][ci]
+    // D[row = co][col = ci]: lane = ci, registers = co 8g + 4h + i; gwp[copy][tap][co][ci].
+    // Workgroups are dealt round-robin to the 8 XCDs by linear id: with one copy per residue mod 8
+    // every atomic stays inside one XCD's L2 instead of being a cross-XCD (memory-side) atomic.
+    float* gcopy = gwp + (size_t)((blockIdx.y * gridDim.x + blockIdx.x) & 7) * (15 * 32 * 32);
 #pragma unroll
     for (int kh = 0; kh < 3; ++kh) {
         const int tap = kh * 5 + wave;
 #pragma unroll
         for (int q = 0; q < 16; ++q) {
             const int co = 8 * (q >> 2) + 4 * h + (q & 3);
-            atomicAdd(gwp + (tap * 32 + co) * 32 + r, acc[kh][q]);
+            atomicAdd(gcopy + (tap * 32 + co) * 32 + r, acc[kh][q]);
         }
     }
 }
@@ -347,7 +393,10 @@ __global__ void conv_wgrad_unpack_kernel(const float* __restrict__ gwp, float* _
     const int i = blockIdx.x * blockDim.x + threadIdx.x;  // over [co][ci][kh][kw]
     if (i >= 32 * 32 * 15) return;
     const int tap = i % 15, ci = (i / 15) % 32, co = i / (15 * 32);
-    gw[i] += gwp[(tap * 32 + co) * 32 + ci];
+    float sum = 0.f;
+#pragma unroll
+    for (int c = 0; c < 8; ++c) sum += gwp[c * (15 * 32 * 32) + (tap * 32 + co) * 32 + ci];
+    gw[i] += sum;
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -699,7 +748,7 @@ extern "C" int sp_conv3x5_wgrad(const void* a_src, const float* a_coef, int a_mo
     SP_CHECK_ARG(a_src && g && y && g_coef && gwp_ws && gw, "sp_conv3x5_wgrad: null pointer");
     SP_CHECK_ARG(a_mode == IN_ID || (a_mode == IN_BNRELU && a_coef), "sp_conv3x5_wgrad: bad activation mode");
     hipStream_t s = (hipStream_t)stream;
-    hipError_t e = hipMemsetAsync(gwp_ws, 0, 15 * 32 * 32 * sizeof(float), s);
+    hipError_t e = hipMemsetAsync(gwp_ws, 0, 8 * 15 * 32 * 32 * sizeof(float), s);
     if (e != hipSuccess) return fail(SP_ELAUNCH, "sp_conv3x5_wgrad: %s", hipGetErrorString(e));
     const int fsplit = F >= 8 ? 2 : 1;
     dim3 grid((T + 63) / 64, B * fsplit), blk(320);

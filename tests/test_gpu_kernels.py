@@ -438,7 +438,7 @@ def test_conv_kernels_individually(cuda, shape):
     out = cs._conv(gten, yten, coef3, cs.IN_BNBWD, cs._pack(w, 1), None, aten, None, cs.EPI_ADD, B, Fq, T)
     assert _relmax(out, ref_gin.permute(0, 2, 3, 1) + aten.float()) <= 1e-2
     # --- weight gradient, activation = relu(BN(a_src)) and identity
-    ws = torch.empty(15 * 32 * 32, device=cuda)
+    ws = torch.empty(8 * 15 * 32 * 32, device=cuda)
     for mode in (cs.IN_BNRELU, cs.IN_ID):
         act = _bf(torch.relu(coef2[:32] * aten.float() + coef2[32:])).float() if mode == cs.IN_BNRELU else aten.float()
         ref_gw = torch.nn.grad.conv2d_weight(act.permute(0, 3, 1, 2).contiguous(), (32, 32, 3, 5), gy_nchw, padding=(1, 2))

@@ -185,10 +185,11 @@ int sp_block_bwd_in(const void* gz, const void* z, int64_t zsb, int64_t zsf, int
  * in dtype (SP_F32 / SP_BF16), rows re-ordered from c*F + f to f*C + c (C = 1: unchanged; F = n_in/C)
  * -- the order the conv stack hands its features over in (net.py:81-83).  sp_sru_unpack_dw: the
  * inverse for the gradient, summing S split-K partials [S][n_in][k][dir][d] of dtype into f32
- * dweight[n_in][dir][d][k] (overwritten). */
+ * dweight[n_in][dir][d][k] (overwritten, or added to when accumulate != 0: the caller's gradient
+ * buffer). */
 int sp_sru_pack_w(const float* weight, int n_in, int d, int k, int C, int dtype, void* out, void* stream);
 int sp_sru_unpack_dw(const void* partials, int S, int n_in, int d, int k, int C, int dtype,
-                     float* dweight, void* stream);
+                     int accumulate, float* dweight, void* stream);
 
 /* ---------------------------------------------------------------------------------------
  * Row LayerNorm.  Replaces the layer norms of net.py:61-76 (sru.SRU(layer_norm=True) on every

@@ -87,6 +87,7 @@ class _ConvStackFn(torch.autograd.Function):
                 saved.append((x, y1, y2, z, zs, coef1, save1, save2, c1w, c2w, b1w, b2w))
                 x = z
         ctx.saved = saved
+        ctx.params = (stem_w, stem_b) + tuple(params)
         ctx.spec = spec
         ctx.dims = (B, Fin, Tin, F, T, nblk)
         ctx.training = training
@@ -103,14 +104,22 @@ class _ConvStackFn(torch.autograd.Function):
         if gz.dtype != torch.bfloat16:
             gz = gz.to(torch.bfloat16)
         grads = []
+        from . import ops
+        sink = ops._sink
+        P = ctx.params
+        direct = sink is not None and sink.ok(*P)   # accumulate straight into the parameters' .grad
         with torch.cuda.device(dev):
             s = stream_ptr()
             ws = torch.empty(8 * 15 * 32 * 32, dtype=torch.float32, device=dev)
             for i in range(nblk - 1, -1, -1):
                 x, y1, y2, z, zs, coef1, save1, save2, c1w, c2w, b1w, b2w = ctx.saved[i]
-                z32 = lambda: torch.zeros(32, dtype=torch.float32, device=dev)  # noqa: E731
-                gg1, gb1, gg2, gb2 = z32(), z32(), z32(), z32()
-                gw1, gw2 = torch.zeros_like(c1w), torch.zeros_like(c2w)
+                if direct:
+                    pc1w, pc1b, pb1w, pb1b, pc2w, pc2b, pb2w, pb2b = P[2 + 8 * i: 10 + 8 * i]
+                    gw1, gg1, gb1, gw2, gg2, gb2 = pc1w.grad, pb1w.grad, pb1b.grad, pc2w.grad, pb2w.grad, pb2b.grad
+                else:
+                    small = torch.zeros(6, 32, dtype=torch.float32, device=dev)
+                    gg1, gb1, gg2, gb2, zb1, zb2 = small.unbind(0)
+                    gw1, gw2 = torch.zeros_like(c1w), torch.zeros_like(c2w)
                 sums = torch.empty(64, dtype=torch.float32, device=dev)
                 c3_2 = torch.empty(96, dtype=torch.float32, device=dev)
                 c3_1 = torch.empty(96, dtype=torch.float32, device=dev)
@@ -129,13 +138,22 @@ class _ConvStackFn(torch.autograd.Function):
                 check(lib().sp_conv3x5_wgrad(ptr(x), None, IN_ID, ptr(g1pre), ptr(y1), ptr(c3_1), B, F, T,
                                              ptr(ws), ptr(gw1), s), "sp_conv3x5_wgrad")
                 # a conv bias feeding batch-statistics BatchNorm has an identically zero gradient
-                grads = [gw1, z32(), gg1, gb1, gw2, z32(), gg2, gb2] + grads
+                if direct:
+                    grads = [None] * 8 + grads
+                else:
+                    grads = [gw1, zb1, gg1, gb1, gw2, zb2, gg2, gb2] + grads
                 gz = gx
-            gsw = torch.zeros(32 * 9, dtype=torch.float32, device=dev)
-            gsb = torch.zeros(32, dtype=torch.float32, device=dev)
+            if direct:
+                gsw, gsb = P[0].grad, P[1].grad
+            else:
+                gsw = torch.zeros(32 * 9, dtype=torch.float32, device=dev)
+                gsb = torch.zeros(32, dtype=torch.float32, device=dev)
             check(lib().sp_conv_stem_bwd(ptr(ctx.spec), ptr(gz), B, Fin, Tin, ptr(gsw), ptr(gsb), s),
                   "sp_conv_stem_bwd")
         ctx.saved = None
+        if direct:
+            sink.ready(*P)
+            return (None, None, None, None, None, None, *grads, *([None] * (4 * nblk)))
         return (None, None, None, None, gsw.view(32, 1, 3, 3), gsb, *grads, *([None] * (4 * nblk)))
 
 

@@ -889,7 +889,7 @@ __global__ __launch_bounds__(256) void sru_pack_w_kernel(const float* __restrict
 
 template <typename T, int K>
 __global__ __launch_bounds__(256) void sru_unpack_dw_kernel(const T* __restrict__ part, int S, int n_in, int d,
-                                                            int C, float* __restrict__ dw) {
+                                                            int C, int accumulate, float* __restrict__ dw) {
     const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
     if (i >= (int64_t)n_in * 2 * d) return;
     const int dd = (int)(i % d), dir = (int)((i / d) & 1), r_out = (int)(i / (2 * d));
@@ -906,7 +906,7 @@ __global__ __launch_bounds__(256) void sru_unpack_dw_kernel(const T* __restrict_
     }
     float* dst = dw + (((int64_t)r_in * 2 + dir) * d + dd) * K;
 #pragma unroll
-    for (int kk = 0; kk < K; ++kk) dst[kk] = acc[kk];
+    for (int kk = 0; kk < K; ++kk) dst[kk] = accumulate ? dst[kk] + acc[kk] : acc[kk];
 }
 
 static int pack_check(const char* fn, int n_in, int d, int k, int C) {
@@ -933,7 +933,7 @@ extern "C" int sp_sru_pack_w(const float* weight, int n_in, int d, int k, int C,
 }
 
 extern "C" int sp_sru_unpack_dw(const void* partials, int S, int n_in, int d, int k, int C, int dtype,
-                                float* dweight, void* stream) {
+                                int accumulate, float* dweight, void* stream) {
     using namespace sp;
     int rc = pack_check("sp_sru_unpack_dw", n_in, d, k, C);
     if (rc) return rc;
@@ -941,7 +941,7 @@ extern "C" int sp_sru_unpack_dw(const void* partials, int S, int n_in, int d, in
     SP_CHECK_ARG(dtype == SP_F32 || dtype == SP_BF16, "sp_sru_unpack_dw: dtype %d", dtype);
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
     const unsigned blocks = (unsigned)(((int64_t)n_in * 2 * d + 255) / 256);
-#define SP_UNPACK(T, K) hipLaunchKernelGGL((sru_unpack_dw_kernel<T, K>), dim3(blocks), dim3(256), 0, s, (const T*)partials, S, n_in, d, C, dweight)
+#define SP_UNPACK(T, K) hipLaunchKernelGGL((sru_unpack_dw_kernel<T, K>), dim3(blocks), dim3(256), 0, s, (const T*)partials, S, n_in, d, C, accumulate, dweight)
     if (dtype == SP_F32) { if (k == 3) SP_UNPACK(float, 3); else SP_UNPACK(float, 4); }
     else { if (k == 3) SP_UNPACK(__hip_bfloat16, 3); else SP_UNPACK(__hip_bfloat16, 4); }
 #undef SP_UNPACK

@@ -227,11 +227,14 @@ def sru_fwd(U, xres, wc, bias, mask, T, B, d, k):
     return h, c
 
 
-def sru_bwd(U, xres, wc, bias, mask, c, gh, T, B, d, k):
+def sru_bwd(U, xres, wc, bias, mask, c, gh, T, B, d, k, gwc=None, gbias=None):
+    """gwc / gbias: optional f32 [4d] buffers the kernel ACCUMULATES into (default: fresh zeros)."""
     gU = torch.empty_like(U)
     gx = torch.empty((T, B, 2 * d), dtype=U.dtype, device=U.device) if k == 3 else None
-    gwc = torch.zeros(4 * d, dtype=torch.float32, device=U.device)
-    gbias = torch.zeros(4 * d, dtype=torch.float32, device=U.device)
+    if gwc is None:
+        gwc = torch.zeros(4 * d, dtype=torch.float32, device=U.device)
+    if gbias is None:
+        gbias = torch.zeros(4 * d, dtype=torch.float32, device=U.device)
     with torch.cuda.device(U.device):
         check(lib().sp_sru_bwd(ptr(U), ptr(xres), ptr(wc), ptr(bias), ptr(mask), ptr(c), ptr(gh), T, B,
                                d, k, _lib.dtype_code(U), ptr(gU), ptr(gx), ptr(gwc), ptr(gbias),
@@ -281,16 +284,49 @@ def layernorm_fwd(x2d, gamma, beta, eps):
     return y, mean, rstd
 
 
-def layernorm_bwd(gy2d, x2d, mean, rstd, gamma, gres2d=None):
+def layernorm_bwd(gy2d, x2d, mean, rstd, gamma, gres2d=None, dgamma=None, dbeta=None):
+    """dgamma / dbeta: optional f32 [N] buffers the kernel ACCUMULATES into (default: fresh zeros)."""
     M, N = x2d.shape
     gx = torch.empty_like(x2d)
-    dgamma = torch.zeros(N, dtype=torch.float32, device=x2d.device)
-    dbeta = torch.zeros(N, dtype=torch.float32, device=x2d.device)
+    if dgamma is None:
+        dgamma = torch.zeros(N, dtype=torch.float32, device=x2d.device)
+    if dbeta is None:
+        dbeta = torch.zeros(N, dtype=torch.float32, device=x2d.device)
     with torch.cuda.device(x2d.device):
         check(lib().sp_layernorm_bwd(ptr(gy2d), ptr(x2d), ptr(mean), ptr(rstd), ptr(gamma), ptr(gres2d), M, N,
                                      _lib.dtype_code(x2d), ptr(gx), ptr(dgamma), ptr(dbeta), stream_ptr()),
               "sp_layernorm_bwd")
     return gx, dgamma, dbeta
+
+
+class GradSink:
+    """Active inside train.train_step while every parameter's .grad is a pre-allocated, zeroed f32 view
+    of the optimizer's flat gradient arena (train.FlatAdam).  The backward kernels that accumulate
+    (float atomics, `+=` epilogues) then write straight into p.grad and the autograd functions return
+    None for those inputs: no zero-fill of a temporary and no `p.grad += g` kernel per parameter.
+    `dp` (train.BucketedAllReduce) is told about every parameter finished this way, since autograd's
+    post-accumulate hooks do not fire for it."""
+
+    def __init__(self, dp=None):
+        self.dp = dp
+
+    @staticmethod
+    def ok(*params):
+        return all(p is not None and p.grad is not None and p.grad.dtype == torch.float32 and
+                   p.grad.is_contiguous() and p.dtype == torch.float32 for p in params)
+
+    def ready(self, *params):
+        if self.dp is not None:
+            for p in params:
+                self.dp.param_ready(p)
+
+
+_sink = None
+
+
+def set_grad_sink(sink):
+    global _sink
+    _sink = sink
 
 
 class _LayerNormFn(torch.autograd.Function):
@@ -301,12 +337,20 @@ class _LayerNormFn(torch.autograd.Function):
         y, mean, rstd = layernorm_fwd(x2, g32, b32, eps)
         ctx.save_for_backward(x2, mean, rstd, g32)
         ctx.pdt = (gamma.dtype, beta.dtype)
+        ctx.params = (gamma, beta)
         return y.view(x.shape)
 
     @staticmethod
     def backward(ctx, gy):
         x2, mean, rstd, g32 = ctx.saved_tensors
-        gx, dg, db = layernorm_bwd(gy.contiguous().view(x2.shape).to(x2.dtype), x2, mean, rstd, g32)
+        gyv = gy.contiguous().view(x2.shape).to(x2.dtype)
+        sink = _sink
+        if sink is not None and sink.ok(*ctx.params):
+            gamma, beta = ctx.params
+            gx, _, _ = layernorm_bwd(gyv, x2, mean, rstd, g32, None, gamma.grad, beta.grad)
+            sink.ready(gamma, beta)
+            return gx.view(gy.shape), None, None, None
+        gx, dg, db = layernorm_bwd(gyv, x2, mean, rstd, g32)
         return gx.view(gy.shape), dg.to(ctx.pdt[0]), db.to(ctx.pdt[1]), None
 
 
@@ -324,13 +368,16 @@ def sru_pack_w(weight, d, k, C, dtype):
     return out
 
 
-def sru_unpack_dw(partials, n_in, d, k, C):
-    """split-K partials [S, n_in, k*2*d] -> f32 dweight [n_in, 2*d*k] in the state_dict layout."""
+def sru_unpack_dw(partials, n_in, d, k, C, out=None):
+    """split-K partials [S, n_in, k*2*d] -> f32 dweight [n_in, 2*d*k] in the state_dict layout; with
+    `out` (the parameter's gradient buffer) the sum is ADDED to it."""
     S = partials.shape[0]
-    out = torch.empty((n_in, 2 * d * k), dtype=torch.float32, device=partials.device)
+    acc = out is not None
+    if out is None:
+        out = torch.empty((n_in, 2 * d * k), dtype=torch.float32, device=partials.device)
     with torch.cuda.device(partials.device):
-        check(lib().sp_sru_unpack_dw(ptr(partials), S, n_in, d, k, C, _lib.dtype_code(partials), ptr(out),
-                                     stream_ptr()), "sp_sru_unpack_dw")
+        check(lib().sp_sru_unpack_dw(ptr(partials), S, n_in, d, k, C, _lib.dtype_code(partials), int(acc),
+                                     ptr(out), stream_ptr()), "sp_sru_unpack_dw")
     return out
 
 
@@ -380,6 +427,7 @@ class _SRULayerFn(torch.autograd.Function):
         ctx.save_for_backward(x2, xn, mean, rstd, g32, wk, U, wc32, bs32, mask, c)
         ctx.dims = (T, B, d, k, n_in, C)
         ctx.pdt = (ln_w.dtype, ln_b.dtype, weight.dtype, wc.dtype, bias.dtype)
+        ctx.params = (ln_w, ln_b, weight, wc, bias)
         return h
 
     @staticmethod
@@ -387,16 +435,29 @@ class _SRULayerFn(torch.autograd.Function):
         x2, xn, mean, rstd, g32, wk, U, wc32, bs32, mask, c = ctx.saved_tensors
         T, B, d, k, n_in, C = ctx.dims
         gh = gh.contiguous().to(x2.dtype)
-        gU, gxres, gwc, gbias = sru_bwd(U, x2 if k == 3 else None, wc32, bs32, mask, c, gh, T, B, d, k)
+        ln_w, ln_b, weight, wc, bias = ctx.params
+        sink = _sink
+        direct = sink is not None and sink.ok(ln_w, ln_b, weight, wc, bias)
+        gU, gxres, gwc, gbias = sru_bwd(U, x2 if k == 3 else None, wc32, bs32, mask, c, gh, T, B, d, k,
+                                        wc.grad.view(-1) if direct else None, bias.grad.view(-1) if direct else None)
         gU2 = gU.view(T * B, -1)
         M = T * B
         S = 4 if (M % 4 == 0 and M >= 4096) else 1
-        gw = sru_unpack_dw(_splitk_dw(xn, gU2, S), n_in, d, k, C)
+        gw = sru_unpack_dw(_splitk_dw(xn, gU2, S), n_in, d, k, C, weight.grad if direct else None)
         gxn = torch.mm(gU2, wk.t())
-        gx, dg, db = layernorm_bwd(gxn, x2, mean, rstd, g32, gxres.view(T * B, n_in) if k == 3 else None)
+        gres = gxres.view(T * B, n_in) if k == 3 else None
+        ln_direct = direct and C == 1   # layer 0's vectors are stored in the reference's c*F + f order
+        gx, dg, db = layernorm_bwd(gxn, x2, mean, rstd, g32, gres, ln_w.grad if ln_direct else None,
+                                   ln_b.grad if ln_direct else None)
         if C > 1:
             dg, db = dg.view(n_in // C, C).t().reshape(-1), db.view(n_in // C, C).t().reshape(-1)
         p = ctx.pdt
+        if direct:
+            sink.ready(weight, wc, bias)
+            if ln_direct:
+                sink.ready(ln_w, ln_b)
+                return (gx.view(T, B, n_in), None, None, None, None, None, None, None, None, None, None)
+            return (gx.view(T, B, n_in), dg.to(p[0]), db.to(p[1]), None, None, None, None, None, None, None, None)
         return (gx.view(T, B, n_in), dg.to(p[0]), db.to(p[1]), gw.to(p[2]), gwc.to(p[3]), gbias.to(p[4]),
                 None, None, None, None, None)
 

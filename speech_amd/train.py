@@ -137,19 +137,36 @@ class BucketedAllReduce:
                 hi, count = lo, 0
         self.pending = [b[2] for b in self.buckets]
         self.handles = []
+        self.done = set()
+        self.hooks = [self._make_hook(idx) for idx in range(len(opt.plist))]
+        # keyed by storage address: inside autograd functions a parameter may arrive as another Python
+        # wrapper of the same tensor
+        self.index_of = {p.data_ptr(): idx for idx, p in enumerate(opt.plist)}
         for idx, p in enumerate(opt.plist):
-            p.register_post_accumulate_grad_hook(self._make_hook(idx))
+            p.register_post_accumulate_grad_hook(self.hooks[idx])
         # start from identical replicas
         dist.broadcast(opt.flat, src=0, group=group)
 
     def _make_hook(self, idx):
         def hook(_param):
+            # idempotent within a step: a gradient written straight into the arena is reported by
+            # ops.GradSink, and autograd may still run the parameter's hook with an empty gradient
+            if idx in self.done:
+                return
+            self.done.add(idx)
             b = self.bucket_of[idx]
             self.pending[b] -= 1
             if self.pending[b] == 0:
                 lo, hi, _ = self.buckets[b]
                 self.handles.append(dist.all_reduce(self.opt.flat_grad[lo:hi], group=self.group, async_op=True))
         return hook
+
+    def param_ready(self, p):
+        """For gradients a backward kernel wrote straight into the arena (ops.GradSink): autograd's
+        post-accumulate hook does not fire for them."""
+        idx = self.index_of.get(p.data_ptr())
+        if idx is not None:
+            self.hooks[idx](p)
 
     def finish(self):
         """Call after backward: launch whatever did not fire (unused parameters), wait for all."""
@@ -160,6 +177,7 @@ class BucketedAllReduce:
         for h in self.handles:
             h.wait()
         self.handles = []
+        self.done = set()
         self.pending = [b[2] for b in self.buckets]
 
 
@@ -168,13 +186,20 @@ def train_step(model, optimizer, spectrograms, labels, label_lengths, clip_grad_
     """One optimisation step on a featurised batch (train.py:62-87).  Returns the loss tensor
     (device, no sync)."""
     optimizer.zero_grad()
-    output = model(spectrograms)                                   # [B, T', V]
-    B, Tp, _ = output.shape
-    # train.py:72-74: every utterance is scored over all T' (padded) encoder frames
-    input_lengths = torch.full((B,), Tp, dtype=torch.int32, device=output.device)
-    loss = ops.ctc_loss(output.float(), labels, input_lengths, label_lengths, blank=0,
-                        max_label_len=max_label_len)
-    loss.backward()
+    # FlatAdam: every .grad is a zeroed view of the flat arena, so accumulating backward kernels may
+    # write straight into it (ops.GradSink) instead of through a temporary and an add per parameter
+    sink = ops.GradSink(dp) if isinstance(optimizer, FlatAdam) else None
+    ops.set_grad_sink(sink)
+    try:
+        output = model(spectrograms)                                   # [B, T', V]
+        B, Tp, _ = output.shape
+        # train.py:72-74: every utterance is scored over all T' (padded) encoder frames
+        input_lengths = torch.full((B,), Tp, dtype=torch.int32, device=output.device)
+        loss = ops.ctc_loss(output.float(), labels, input_lengths, label_lengths, blank=0,
+                            max_label_len=max_label_len)
+        loss.backward()
+    finally:
+        ops.set_grad_sink(None)
     world = 1
     if dp is not None:
         dp.finish()

@@ -101,12 +101,13 @@ class SRUCell(nn.Module):
             v = v.view(C, Fq).t().reshape(-1)
         return v.to(dtype)
 
-    def forward(self, x):
+    def forward(self, x, mask=None):
+        """mask: optional pre-drawn variational dropout mask [B, 2d] (already / keep); SRU.forward draws
+        the masks of all layers in one call."""
         T, B, n_in = x.shape
         d = self.hidden_size
         ln = self.layer_norm
-        mask = None
-        if self.training and self.dropout > 0:
+        if mask is None and self.training and self.dropout > 0:
             keep = 1.0 - self.dropout
             mask = torch.bernoulli(torch.full((B, 2 * d), keep, device=x.device)) / keep
         C = self.in_layout[0] if self.in_layout is not None else 1
@@ -131,8 +132,18 @@ class SRU(nn.Module):
             for i in range(num_layers))
 
     def forward(self, x):
-        for cell in self.rnn_lst:
-            x = cell(x)
+        masks = None
+        drops = [c.dropout for c in self.rnn_lst]
+        if self.training and any(p > 0 for p in drops):
+            # every layer's variational mask in three launches instead of three per layer
+            B, d2 = x.shape[1], self.rnn_lst[0].output_size
+            keep = getattr(self, "_keep", None)
+            if keep is None or keep.device != x.device or keep.shape[0] != len(drops):
+                keep = self._keep = torch.tensor([1.0 - p for p in drops], device=x.device).view(-1, 1, 1)
+            masks = torch.bernoulli(keep.expand(len(drops), B, d2)) / keep
+        for i, cell in enumerate(self.rnn_lst):
+            m = masks[i] if masks is not None and drops[i] > 0 else None
+            x = cell(x, m)
         return x, None
 
 

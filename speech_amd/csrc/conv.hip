@@ -79,6 +79,10 @@ __global__ void conv_pack_kernel(const float* __restrict__ w, int bwd_data, __hi
 // ---------------------------------------------------------------------------------------------
 constexpr int kTP = 64, kFR = 4, kPW = kTP + 4, kRows = kFR + 2, kPStr = 40;  // bf16 elems / position
 
+// Persistent: a workgroup keeps the weights in registers and walks tiles (4 f-rows x 64 positions)
+// with stride gridDim.x.  The next tile's input strip (and this tile's epilogue source) is requested
+// before this tile's MFMAs, so one HBM round trip is hidden behind a tile of matrix work; per tile
+// two barriers (strip written / strip no longer read).
 template <int IN_MODE, int EPI>
 __global__ __launch_bounds__(256, 2) void conv3x5_kernel(
     const __hip_bfloat16* __restrict__ in, const __hip_bfloat16* __restrict__ in2,
@@ -87,35 +91,44 @@ __global__ __launch_bounds__(256, 2) void conv3x5_kernel(
     const float* __restrict__ epi_coef, int B, int F, int T, __hip_bfloat16* __restrict__ out) {
     __shared__ __attribute__((aligned(16))) __hip_bfloat16 tile[kRows * kPW * kPStr];
     __shared__ __attribute__((aligned(16))) __hip_bfloat16 otile[kFR * kTP * kPStr];
+    __shared__ __attribute__((aligned(16))) float scoef[5][32];   // input c0 c1 c2 | mask e0 e1
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int r = lane & 31, h = lane >> 5;
-    const int t0 = blockIdx.x * kTP, f0 = blockIdx.y * kFR, b = blockIdx.z;
-    const int64_t img = (int64_t)b * F * T;
+    const int ch4 = tid & 3;
+    const int ntx = (T + kTP - 1) / kTP, nfy = (F + kFR - 1) / kFR;
+    const int ntiles = ntx * nfy * B;
 
-    // ---- stage the input strip (transform on the way) ----
-    {
-        const int ch4 = tid & 3;
-        float c0[8], c1[8], c2[8];
-        if (IN_MODE != IN_ID) {
+    if (tid < 96) scoef[tid >> 5][tid & 31] = (IN_MODE != IN_ID && (IN_MODE == IN_BNBWD || tid < 64)) ? coef[tid] : 0.f;
+    else if (tid < 160) scoef[3 + ((tid - 96) >> 5)][tid & 31] = (EPI == EPI_MASK) ? epi_coef[tid - 96] : 0.f;
+    // ---- weights: the whole 32x480 matrix in registers (30 fragments), once per workgroup ----
+    bf16x8 wreg[30];
 #pragma unroll
-            for (int j = 0; j < 8; ++j) {
-                c0[j] = coef[ch4 * 8 + j];
-                c1[j] = coef[32 + ch4 * 8 + j];
-                c2[j] = (IN_MODE == IN_BNBWD) ? coef[64 + ch4 * 8 + j] : 0.f;
-            }
-        }
-        // all of the strip's loads are issued before the first is used (7 x 16 bytes per thread, 14 in
-        // the BN-backward mode): one HBM round trip per block instead of seven
-        constexpr int NIT = (kRows * kPW * 4 + 255) / 256;
-        uint4 v[NIT], v2[NIT];
-        bool ok[NIT];
+    for (int i = 0; i < 30; ++i)
+        wreg[i] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const uint4*>(wpack + ((int64_t)i * 64 + lane) * 8));
+    float bq[16];
+#pragma unroll
+    for (int q = 0; q < 16; ++q) bq[q] = (EPI == EPI_NONE && bias) ? bias[8 * (q >> 2) + 4 * h + (q & 3)] : 0.f;
+
+    constexpr int NIT = (kRows * kPW * 4 + 255) / 256;
+    uint4 v[NIT], v2[NIT];
+    bool ok[NIT];
+    auto decode = [&](int tl, int& t0, int& f0, int64_t& img) {
+        const int tx = tl % ntx, rest = tl / ntx;
+        t0 = tx * kTP;
+        f0 = (rest % nfy) * kFR;
+        img = (int64_t)(rest / nfy) * F * T;
+    };
+    auto load_strip = [&](int tl) {   // global -> registers, nothing waits on it here
+        int t0, f0;
+        int64_t img;
+        decode(tl, t0, f0, img);
 #pragma unroll
         for (int it = 0; it < NIT; ++it) {
             const int id = tid + it * 256;
             const int row = id / (kPW * 4);
             const int pos = (id - row * (kPW * 4)) >> 2;
             const int f = f0 - 1 + row, t = t0 - 2 + pos;
-            ok[it] = id < kRows * kPW * 4 && f >= 0 && f < F && t >= 0 && t < T;
+            ok[it] = tl < ntiles && id < kRows * kPW * 4 && f >= 0 && f < F && t >= 0 && t < T;
             v[it] = make_uint4(0, 0, 0, 0);
             v2[it] = make_uint4(0, 0, 0, 0);
             if (ok[it]) {
@@ -124,6 +137,11 @@ __global__ __launch_bounds__(256, 2) void conv3x5_kernel(
                 if (IN_MODE == IN_BNBWD) v2[it] = *reinterpret_cast<const uint4*>(in2 + off);
             }
         }
+    };
+    auto store_strip = [&]() {   // registers -> LDS with the producer's transform applied
+        const float* c0 = scoef[0] + ch4 * 8;
+        const float* c1 = scoef[1] + ch4 * 8;
+        const float* c2 = scoef[2] + ch4 * 8;
 #pragma unroll
         for (int it = 0; it < NIT; ++it) {
             const int id = tid + it * 256;
@@ -147,85 +165,88 @@ __global__ __launch_bounds__(256, 2) void conv3x5_kernel(
             if (!ok[it]) o = make_uint4(0, 0, 0, 0);   // zero padding is applied AFTER the transform
             if (id < kRows * kPW * 4) *reinterpret_cast<uint4*>(tile + (row * kPW + pos) * kPStr + ch4 * 8) = o;
         }
-    }
-    // ---- weights: the whole 32x480 matrix in registers (30 fragments) ----
-    bf16x8 wreg[30];
-#pragma unroll
-    for (int i = 0; i < 30; ++i)
-        wreg[i] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const uint4*>(wpack + ((int64_t)i * 64 + lane) * 8));
-    __syncthreads();
+    };
 
-    const int f = f0 + wave;
-    f32x16 acc[2];
-#pragma unroll
-    for (int m = 0; m < 2; ++m)
-#pragma unroll
-        for (int q = 0; q < 16; ++q)
-            acc[m][q] = (EPI == EPI_NONE && bias) ? bias[8 * (q >> 2) + 4 * h + (q & 3)] : 0.f;
-
-#pragma unroll
-    for (int kh = 0; kh < 3; ++kh) {
-#pragma unroll
-        for (int kw = 0; kw < 5; ++kw) {
-#pragma unroll
-            for (int half = 0; half < 2; ++half) {
-#pragma unroll
-                for (int m = 0; m < 2; ++m) {
-                    const __hip_bfloat16* p = tile + ((wave + kh) * kPW + m * 32 + r + kw) * kPStr + (half * 2 + h) * 8;
-                    const bf16x8 bfrag = __builtin_bit_cast(bf16x8, *reinterpret_cast<const uint4*>(p));
-                    acc[m] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wreg[(kh * 5 + kw) * 2 + half], bfrag, acc[m], 0, 0, 0);
-                }
-            }
-        }
-    }
-    if (f >= F) return;
-    // ---- epilogue ----
-    // The MFMA leaves lane = position, registers = 16 of its channels (8g + 4h + i): stored directly
-    // that is 8 bytes per lane into 32 different cache lines per instruction.  Each wave therefore
-    // transposes its 64 x 32 output through its own LDS slab and then works in 16-byte chunks
-    // (4 lanes = one position's 64 bytes, consecutive positions in consecutive lanes): epilogue
-    // source loads and output stores are 1 KiB contiguous per instruction.
-    __hip_bfloat16* slab = otile + wave * (kTP * kPStr);
-#pragma unroll
-    for (int m = 0; m < 2; ++m) {
-#pragma unroll
-        for (int g = 0; g < 4; ++g)
-            *reinterpret_cast<uint2*>(slab + (m * 32 + r) * kPStr + 8 * g + 4 * h) =
-                pack4(acc[m][4 * g], acc[m][4 * g + 1], acc[m][4 * g + 2], acc[m][4 * g + 3]);
-    }
-    __builtin_amdgcn_wave_barrier();
-    {
-        const int ch4 = lane & 3;
-        float e0[8], e1[8];
-        if (EPI == EPI_MASK) {
-#pragma unroll
-            for (int j = 0; j < 8; ++j) { e0[j] = epi_coef[ch4 * 8 + j]; e1[j] = epi_coef[32 + ch4 * 8 + j]; }
-        }
+    // The BN-backward strip is two tensors (56 VGPRs): held across the MFMAs it pushes the kernel past
+    // 256 registers, so only the single-tensor modes prefetch the next tile's strip.
+    constexpr bool kPrefetch = IN_MODE != IN_BNBWD;
+    __syncthreads();   // scoef
+    int tl = blockIdx.x;
+    if (kPrefetch) load_strip(tl);
+    for (; tl < ntiles; tl += gridDim.x) {
+        int t0, f0;
+        int64_t img;
+        decode(tl, t0, f0, img);
+        if (!kPrefetch) load_strip(tl);
+        store_strip();
+        __syncthreads();                 // strip of this tile is in LDS
+        if (kPrefetch) load_strip(tl + gridDim.x);   // next tile's strip: lands during the MFMAs below
+        const int f = f0 + wave;
+        // epilogue source of this tile, requested before the matrix work
         uint4 ev[4];
 #pragma unroll
         for (int it = 0; it < 4; ++it) {
             const int pos = it * 16 + (lane >> 2), t = t0 + pos;
             ev[it] = make_uint4(0, 0, 0, 0);
-            if (EPI != EPI_NONE && t < T)
+            if (EPI != EPI_NONE && f < F && t < T)
                 ev[it] = *reinterpret_cast<const uint4*>(epi_src + (img + (int64_t)f * T + t) * kC + ch4 * 8);
         }
+        f32x16 acc[2];
 #pragma unroll
-        for (int it = 0; it < 4; ++it) {
-            const int pos = it * 16 + (lane >> 2), t = t0 + pos;
-            uint4 o = *reinterpret_cast<const uint4*>(slab + pos * kPStr + ch4 * 8);
-            if (EPI != EPI_NONE) {
-                float v[8], e[8];
-                unpack8(o, v);
-                unpack8(ev[it], e);
+        for (int m = 0; m < 2; ++m)
 #pragma unroll
-                for (int j = 0; j < 8; ++j) {
-                    if (EPI == EPI_MASK) v[j] = (e0[j] * e[j] + e1[j] > 0.f) ? v[j] : 0.f;
-                    else v[j] += e[j];
+            for (int q = 0; q < 16; ++q) acc[m][q] = bq[q];
+#pragma unroll
+        for (int kh = 0; kh < 3; ++kh) {
+#pragma unroll
+            for (int kw = 0; kw < 5; ++kw) {
+#pragma unroll
+                for (int half = 0; half < 2; ++half) {
+#pragma unroll
+                    for (int m = 0; m < 2; ++m) {
+                        const __hip_bfloat16* p = tile + ((wave + kh) * kPW + m * 32 + r + kw) * kPStr + (half * 2 + h) * 8;
+                        const bf16x8 bfrag = __builtin_bit_cast(bf16x8, *reinterpret_cast<const uint4*>(p));
+                        acc[m] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wreg[(kh * 5 + kw) * 2 + half], bfrag, acc[m], 0, 0, 0);
+                    }
                 }
-                o = pack8(v);
             }
-            if (t < T) *reinterpret_cast<uint4*>(out + (img + (int64_t)f * T + t) * kC + ch4 * 8) = o;
         }
+        // ---- epilogue ----
+        // The MFMA leaves lane = position, registers = 16 of its channels (8g + 4h + i): stored directly
+        // that is 8 bytes per lane into 32 different cache lines per instruction.  Each wave therefore
+        // transposes its 64 x 32 output through its own LDS slab and then works in 16-byte chunks
+        // (4 lanes = one position's 64 bytes, consecutive positions in consecutive lanes).
+        if (f < F) {
+            __hip_bfloat16* slab = otile + wave * (kTP * kPStr);
+#pragma unroll
+            for (int m = 0; m < 2; ++m) {
+#pragma unroll
+                for (int g = 0; g < 4; ++g)
+                    *reinterpret_cast<uint2*>(slab + (m * 32 + r) * kPStr + 8 * g + 4 * h) =
+                        pack4(acc[m][4 * g], acc[m][4 * g + 1], acc[m][4 * g + 2], acc[m][4 * g + 3]);
+            }
+            __builtin_amdgcn_wave_barrier();
+            const float* e0 = scoef[3] + ch4 * 8;
+            const float* e1 = scoef[4] + ch4 * 8;
+#pragma unroll
+            for (int it = 0; it < 4; ++it) {
+                const int pos = it * 16 + (lane >> 2), t = t0 + pos;
+                uint4 o = *reinterpret_cast<const uint4*>(slab + pos * kPStr + ch4 * 8);
+                if (EPI != EPI_NONE) {
+                    float x[8], e[8];
+                    unpack8(o, x);
+                    unpack8(ev[it], e);
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) {
+                        if (EPI == EPI_MASK) x[j] = (e0[j] * e[j] + e1[j] > 0.f) ? x[j] : 0.f;
+                        else x[j] += e[j];
+                    }
+                    o = pack8(x);
+                }
+                if (t < T) *reinterpret_cast<uint4*>(out + (img + (int64_t)f * T + t) * kC + ch4 * 8) = o;
+            }
+        }
+        __syncthreads();                 // nobody reads this tile's strip any more
     }
 }
 
@@ -726,7 +747,9 @@ extern "C" int sp_conv3x5(const void* in, const void* in2, const float* coef, in
     SP_CHECK_ARG(in_mode != IN_BNBWD || in2, "sp_conv3x5: BN-backward transform needs the second input");
     SP_CHECK_ARG(epi_mode == EPI_NONE || epi_src, "sp_conv3x5: epilogue needs its source tensor");
     SP_CHECK_ARG(epi_mode != EPI_MASK || epi_coef, "sp_conv3x5: mask epilogue needs coefficients");
-    dim3 grid((T + kTP - 1) / kTP, (F + kFR - 1) / kFR, B), blk(256);
+    const int64_t ntiles = (int64_t)((T + kTP - 1) / kTP) * ((F + kFR - 1) / kFR) * B;
+    SP_CHECK_ARG(ntiles < ((int64_t)1 << 30), "sp_conv3x5: too many tiles");
+    dim3 grid((unsigned)(ntiles < 512 ? ntiles : 512)), blk(256);   // persistent: 2 workgroups per CU
     hipStream_t s = (hipStream_t)stream;
 #define SP_CONV_LAUNCH(IM, EP)                                                                          \
     hipLaunchKernelGGL((conv3x5_kernel<IM, EP>), grid, blk, 0, s, (const bf16*)in, (const bf16*)in2, coef, \

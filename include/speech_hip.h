@@ -143,6 +143,8 @@ int sp_adam_step_f32(float* p, const float* g, float* m, float* v, int64_t n, fl
  *   c[64:96] (BatchNorm backward from (dz, y)).  Zero padding applies after tf.  epi_mode 0: none
  *   (forward, bias added); 1: out *= [e[0:32]*epi_src + e[32:64] > 0] (ReLU mask recomputed from
  *   the pre-BN tensor); 2: out += epi_src (residual gradient).  Supported pairs: (0,0) (1,0) (2,1) (2,2).
+ *   bn_sums (may be NULL; zeroed inside): the BatchNorm reduction over the OUTPUT fused into the
+ *   epilogue -- epi_mode 0: what sp_bn_stats(out) gives; epi_mode 1: what sp_bn_bwd_reduce(out, epi_src) gives.
  * sp_conv3x5_wgrad: gw[32][32][3][5] += sum_pos dy[pos][co] * a[pos + tap][ci], with
  *   a = a_src (a_mode 0) or relu(BN(a_src)) (a_mode 1), dy = g_coef affine of (g, y) as in_mode 2.
  *   gwp_ws: 8*15*32*32 f32 scratch (zeroed inside; one partial copy per XCD).
@@ -160,7 +162,7 @@ int sp_adam_step_f32(float* p, const float* g, float* m, float* v, int64_t n, fl
 int sp_conv_pack_w(const float* w, int bwd_data, void* wpack, void* stream);
 int sp_conv3x5(const void* in, const void* in2, const float* coef, int in_mode, const void* wpack,
                const float* bias, const void* epi_src, const float* epi_coef, int epi_mode, int B,
-               int F, int T, void* out, void* stream);
+               int F, int T, void* out, float* bn_sums, void* stream);
 int sp_conv3x5_wgrad(const void* a_src, const float* a_coef, int a_mode, const void* g,
                      const void* y, const float* g_coef, int B, int F, int T, float* gwp_ws,
                      float* gw, void* stream);

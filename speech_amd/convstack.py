@@ -28,21 +28,19 @@ def _pack(w, bwd_data):
     return out
 
 
-def _conv(inp, in2, coef, in_mode, wpack, bias, epi_src, epi_coef, epi_mode, B, F, T):
+def _conv(inp, in2, coef, in_mode, wpack, bias, epi_src, epi_coef, epi_mode, B, F, T, bn_sums=None):
+    """bn_sums: optional f32 [64] receiving the BatchNorm reduction over the output (fused epilogue)."""
     out = torch.empty((B, F, T, C), dtype=torch.bfloat16, device=inp.device)
     check(lib().sp_conv3x5(ptr(inp), ptr(in2), ptr(coef), in_mode, ptr(wpack), ptr(bias), ptr(epi_src),
-                           ptr(epi_coef), epi_mode, B, F, T, ptr(out), stream_ptr()), "sp_conv3x5")
+                           ptr(epi_coef), epi_mode, B, F, T, ptr(out), ptr(bn_sums), stream_ptr()), "sp_conv3x5")
     return out
 
 
-def _bn_fwd(y, npos, bn_w, bn_b, rmean, rvar, momentum, eps, training):
-    dev = y.device
+def _bn_fwd(sums, npos, bn_w, bn_b, rmean, rvar, momentum, eps, training):
+    """sums: the (sum y, sum y^2) the producing convolution's epilogue left (None in eval mode)."""
+    dev = bn_w.device
     coef = torch.empty(64, dtype=torch.float32, device=dev)
     save = torch.empty(64, dtype=torch.float32, device=dev)
-    sums = None
-    if training:
-        sums = torch.empty(64, dtype=torch.float32, device=dev)
-        check(lib().sp_bn_stats(ptr(y), npos, ptr(sums), stream_ptr()), "sp_bn_stats")
     check(lib().sp_bn_finalize_fwd(ptr(sums), npos, ptr(bn_w), ptr(bn_b), ptr(rmean), ptr(rvar), momentum,
                                    eps, int(training), ptr(coef), ptr(save), stream_ptr()), "sp_bn_finalize_fwd")
     return coef, save
@@ -71,10 +69,12 @@ class _ConvStackFn(torch.autograd.Function):
             for i in range(nblk):
                 c1w, c1b, b1w, b1b, c2w, c2b, b2w, b2b = [_f32(p) for p in params[8 * i: 8 * i + 8]]
                 rm1, rv1, rm2, rv2 = bufs[4 * i: 4 * i + 4]
-                y1 = _conv(x, None, None, IN_ID, _pack(c1w, 0), c1b, None, None, EPI_NONE, B, F, T)
-                coef1, save1 = _bn_fwd(y1, npos, b1w, b1b, rm1, rv1, momentum, eps, training)
-                y2 = _conv(y1, None, coef1, IN_BNRELU, _pack(c2w, 0), c2b, None, None, EPI_NONE, B, F, T)
-                coef2, save2 = _bn_fwd(y2, npos, b2w, b2b, rm2, rv2, momentum, eps, training)
+                s1 = torch.empty(64, dtype=torch.float32, device=dev) if training else None
+                s2 = torch.empty(64, dtype=torch.float32, device=dev) if training else None
+                y1 = _conv(x, None, None, IN_ID, _pack(c1w, 0), c1b, None, None, EPI_NONE, B, F, T, s1)
+                coef1, save1 = _bn_fwd(s1, npos, b1w, b1b, rm1, rv1, momentum, eps, training)
+                y2 = _conv(y1, None, coef1, IN_BNRELU, _pack(c2w, 0), c2b, None, None, EPI_NONE, B, F, T, s2)
+                coef2, save2 = _bn_fwd(s2, npos, b2w, b2b, rm2, rv2, momentum, eps, training)
                 last = i == nblk - 1
                 if last:   # [T][B][F*32]
                     z = torch.empty((T, B, F * C), dtype=torch.bfloat16, device=dev)
@@ -128,10 +128,10 @@ class _ConvStackFn(torch.autograd.Function):
                                             ptr(sums), s), "sp_block_bwd_in")
                 check(lib().sp_bn_finalize_bwd(ptr(sums), ptr(save2), ptr(b2w), npos, ptr(c3_2), ptr(gg2),
                                                ptr(gb2), s), "sp_bn_finalize_bwd")
-                g1pre = _conv(g2pre, y2, c3_2, IN_BNBWD, _pack(c2w, 1), None, y1, coef1, EPI_MASK, B, F, T)
+                # (sum g1pre, sum g1pre * y1) for BatchNorm-1's backward comes out of this epilogue
+                g1pre = _conv(g2pre, y2, c3_2, IN_BNBWD, _pack(c2w, 1), None, y1, coef1, EPI_MASK, B, F, T, sums)
                 check(lib().sp_conv3x5_wgrad(ptr(y1), ptr(coef1), IN_BNRELU, ptr(g2pre), ptr(y2), ptr(c3_2),
                                              B, F, T, ptr(ws), ptr(gw2), s), "sp_conv3x5_wgrad")
-                check(lib().sp_bn_bwd_reduce(ptr(g1pre), ptr(y1), npos, ptr(sums), s), "sp_bn_bwd_reduce")
                 check(lib().sp_bn_finalize_bwd(ptr(sums), ptr(save1), ptr(b1w), npos, ptr(c3_1), ptr(gg1),
                                                ptr(gb1), s), "sp_bn_finalize_bwd")
                 gx = _conv(g1pre, y1, c3_1, IN_BNBWD, _pack(c1w, 1), None, g2pre, None, EPI_ADD, B, F, T)

@@ -54,6 +54,10 @@ __device__ __forceinline__ uint2 pack4(float a, float b, float c, float d) {
     return v;
 }
 
+// shuffle-reduce NV values over the 16 lanes of a wave that share (lane & 3); defined below
+template <int NV>
+__device__ __forceinline__ void reduce_ch4(float (&v)[NV]);
+
 enum { IN_ID = 0, IN_BNRELU = 1, IN_BNBWD = 2 };
 enum { EPI_NONE = 0, EPI_MASK = 1, EPI_ADD = 2 };
 
@@ -88,10 +92,15 @@ __global__ __launch_bounds__(256, 2) void conv3x5_kernel(
     const __hip_bfloat16* __restrict__ in, const __hip_bfloat16* __restrict__ in2,
     const float* __restrict__ coef, const __hip_bfloat16* __restrict__ wpack,
     const float* __restrict__ bias, const __hip_bfloat16* __restrict__ epi_src,
-    const float* __restrict__ epi_coef, int B, int F, int T, __hip_bfloat16* __restrict__ out) {
+    const float* __restrict__ epi_coef, int B, int F, int T, __hip_bfloat16* __restrict__ out,
+    float* __restrict__ bn_sums) {
     __shared__ __attribute__((aligned(16))) __hip_bfloat16 tile[kRows * kPW * kPStr];
     __shared__ __attribute__((aligned(16))) __hip_bfloat16 otile[kFR * kTP * kPStr];
     __shared__ __attribute__((aligned(16))) float scoef[5][32];   // input c0 c1 c2 | mask e0 e1
+    __shared__ float sbias[32];
+    // BatchNorm statistics of the OUTPUT, fused: per-thread running sums live in LDS (the accumulators
+    // are free registers only inside the epilogue), [k][thread]: k < 8 first moment, k >= 8 second
+    __shared__ float sstat[16][256];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int r = lane & 31, h = lane >> 5;
     const int ch4 = tid & 3;
@@ -105,9 +114,10 @@ __global__ __launch_bounds__(256, 2) void conv3x5_kernel(
 #pragma unroll
     for (int i = 0; i < 30; ++i)
         wreg[i] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const uint4*>(wpack + ((int64_t)i * 64 + lane) * 8));
-    float bq[16];
+    if (tid < 32) sbias[tid] = (EPI == EPI_NONE && bias) ? bias[tid] : 0.f;
+    const bool stats = bn_sums != nullptr && (EPI == EPI_NONE || EPI == EPI_MASK);
 #pragma unroll
-    for (int q = 0; q < 16; ++q) bq[q] = (EPI == EPI_NONE && bias) ? bias[8 * (q >> 2) + 4 * h + (q & 3)] : 0.f;
+    for (int k = 0; k < 16; ++k) sstat[k][tid] = 0.f;
 
     constexpr int NIT = (kRows * kPW * 4 + 255) / 256;
     uint4 v[NIT], v2[NIT];
@@ -170,6 +180,11 @@ __global__ __launch_bounds__(256, 2) void conv3x5_kernel(
     // The BN-backward strip is two tensors (56 VGPRs): held across the MFMAs it pushes the kernel past
     // 256 registers, so only the single-tensor modes prefetch the next tile's strip.
     constexpr bool kPrefetch = IN_MODE != IN_BNBWD;
+    // running BatchNorm sums: registers where there is room (forward modes), LDS otherwise
+    constexpr bool kStatRegs = EPI == EPI_NONE;
+    float rs[16];
+#pragma unroll
+    for (int k = 0; k < 16; ++k) rs[k] = 0.f;
     __syncthreads();   // scoef
     int tl = blockIdx.x;
     if (kPrefetch) load_strip(tl);
@@ -195,7 +210,7 @@ __global__ __launch_bounds__(256, 2) void conv3x5_kernel(
 #pragma unroll
         for (int m = 0; m < 2; ++m)
 #pragma unroll
-            for (int q = 0; q < 16; ++q) acc[m][q] = bq[q];
+            for (int q = 0; q < 16; ++q) acc[m][q] = sbias[8 * (q >> 2) + 4 * h + (q & 3)];
 #pragma unroll
         for (int kh = 0; kh < 3; ++kh) {
 #pragma unroll
@@ -228,12 +243,16 @@ __global__ __launch_bounds__(256, 2) void conv3x5_kernel(
             __builtin_amdgcn_wave_barrier();
             const float* e0 = scoef[3] + ch4 * 8;
             const float* e1 = scoef[4] + ch4 * 8;
+            float ps[8], pq[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) { ps[j] = 0.f; pq[j] = 0.f; }
 #pragma unroll
             for (int it = 0; it < 4; ++it) {
                 const int pos = it * 16 + (lane >> 2), t = t0 + pos;
                 uint4 o = *reinterpret_cast<const uint4*>(slab + pos * kPStr + ch4 * 8);
+                float e[8];
                 if (EPI != EPI_NONE) {
-                    float x[8], e[8];
+                    float x[8];
                     unpack8(o, x);
                     unpack8(ev[it], e);
 #pragma unroll
@@ -243,10 +262,52 @@ __global__ __launch_bounds__(256, 2) void conv3x5_kernel(
                     }
                     o = pack8(x);
                 }
-                if (t < T) *reinterpret_cast<uint4*>(out + (img + (int64_t)f * T + t) * kC + ch4 * 8) = o;
+                if (t < T) {
+                    *reinterpret_cast<uint4*>(out + (img + (int64_t)f * T + t) * kC + ch4 * 8) = o;
+                    if (stats) {   // on the values as stored (bf16): what a separate reduction pass would read
+                        float x[8];
+                        unpack8(o, x);
+#pragma unroll
+                        for (int j = 0; j < 8; ++j) {
+                            ps[j] += x[j];
+                            pq[j] += (EPI == EPI_MASK) ? x[j] * e[j] : x[j] * x[j];   // (sum g, sum g*y) | (sum y, sum y^2)
+                        }
+                    }
+                }
+            }
+            if (stats) {
+                if (kStatRegs) {
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) { rs[j] += ps[j]; rs[8 + j] += pq[j]; }
+                } else {
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) {
+                        sstat[j][tid] += ps[j];
+                        sstat[8 + j][tid] += pq[j];
+                    }
+                }
             }
         }
         __syncthreads();                 // nobody reads this tile's strip any more
+    }
+    if (stats) {   // workgroup reduction over the threads that share a channel group, 64 atomics per workgroup
+        float a16[16];
+#pragma unroll
+        for (int k = 0; k < 16; ++k) a16[k] = kStatRegs ? rs[k] : sstat[k][tid];
+        reduce_ch4<16>(a16);
+        __syncthreads();
+        float* red = &sstat[0][0];   // reuse as [4 waves][4 groups][16]
+        if (lane < 4) {
+#pragma unroll
+            for (int k = 0; k < 16; ++k) red[(wave * 4 + lane) * 16 + k] = a16[k];
+        }
+        __syncthreads();
+        if (tid < 64) {
+            const int c4 = tid >> 4, k = tid & 15;
+            const float sm = red[(0 * 4 + c4) * 16 + k] + red[(1 * 4 + c4) * 16 + k] + red[(2 * 4 + c4) * 16 + k] +
+                             red[(3 * 4 + c4) * 16 + k];
+            atomicAdd(bn_sums + (k >> 3) * 32 + c4 * 8 + (k & 7), sm);
+        }
     }
 }
 
@@ -739,7 +800,7 @@ extern "C" int sp_conv_pack_w(const float* w, int bwd_data, void* wpack, void* s
 
 extern "C" int sp_conv3x5(const void* in, const void* in2, const float* coef, int in_mode, const void* wpack,
                           const float* bias, const void* epi_src, const float* epi_coef, int epi_mode, int B,
-                          int F, int T, void* out, void* stream) {
+                          int F, int T, void* out, float* bn_sums, void* stream) {
     int rc = check_act("sp_conv3x5", B, F, T);
     if (rc) return rc;
     SP_CHECK_ARG(in && wpack && out, "sp_conv3x5: null pointer");
@@ -751,9 +812,14 @@ extern "C" int sp_conv3x5(const void* in, const void* in2, const float* coef, in
     SP_CHECK_ARG(ntiles < ((int64_t)1 << 30), "sp_conv3x5: too many tiles");
     dim3 grid((unsigned)(ntiles < 512 ? ntiles : 512)), blk(256);   // persistent: 2 workgroups per CU
     hipStream_t s = (hipStream_t)stream;
+    SP_CHECK_ARG(!bn_sums || epi_mode != EPI_ADD, "sp_conv3x5: fused statistics exist for epi_mode 0 and 1");
+    if (bn_sums) {
+        hipError_t e = hipMemsetAsync(bn_sums, 0, 64 * sizeof(float), s);
+        if (e != hipSuccess) return fail(SP_ELAUNCH, "sp_conv3x5: %s", hipGetErrorString(e));
+    }
 #define SP_CONV_LAUNCH(IM, EP)                                                                          \
     hipLaunchKernelGGL((conv3x5_kernel<IM, EP>), grid, blk, 0, s, (const bf16*)in, (const bf16*)in2, coef, \
-                       (const bf16*)wpack, bias, (const bf16*)epi_src, epi_coef, B, F, T, (bf16*)out)
+                       (const bf16*)wpack, bias, (const bf16*)epi_src, epi_coef, B, F, T, (bf16*)out, bn_sums)
     if (in_mode == IN_ID && epi_mode == EPI_NONE) SP_CONV_LAUNCH(IN_ID, EPI_NONE);
     else if (in_mode == IN_BNRELU && epi_mode == EPI_NONE) SP_CONV_LAUNCH(IN_BNRELU, EPI_NONE);
     else if (in_mode == IN_BNBWD && epi_mode == EPI_MASK) SP_CONV_LAUNCH(IN_BNBWD, EPI_MASK);

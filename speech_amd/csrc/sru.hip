@@ -577,7 +577,7 @@ __global__ __launch_bounds__(256) void sru_bwd_split_kernel(
     __shared__ float sG[2][CH][64], sBv[2][CH][64];                                       // r-side -> chain
     __shared__ __attribute__((aligned(16))) unsigned short tg[2][2][CH][64];              // chain -> f-side: g0 | df
     __shared__ __attribute__((aligned(16))) unsigned short tr[2][CH][64];                 // r-side: dr | gx
-    // Measured placement (scratch/ub/hwid.hip): workgroups b and b+256 share a CU, the first one's waves
+    // Measured placement (tools/ubench/hwid.hip): workgroups b and b+256 share a CU, the first one's waves
     // 0..3 sit on SIMDs 0,2,1,3 and the second one's on 2,1,3,0.  Rotating the second one's roles by
     // three puts loader+r-side, r-side+loader, f-side+chain, chain+f-side on the four SIMDs.
     const int rot = ((blockIdx.x >> 8) & 1) * 3;

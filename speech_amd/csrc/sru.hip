@@ -887,6 +887,29 @@ __global__ __launch_bounds__(256) void sru_pack_w_kernel(const float* __restrict
         Elem<T>::st(out + (((int64_t)r_out * K + kk) * 2 + dir) * d + dd, src[kk]);
 }
 
+// Transposed pack: out[n][r_out] (n = (kk*2 + dir)*d + dd, row length n_in), the K-contiguous "B" operand of
+// sp_gemm_nt_bf16.  One workgroup moves 32 rows x 64 dd x K through LDS: reads are 64*K consecutive floats
+// of one weight row, writes are 32 consecutive r_out of one output row.  Needs n_in % 32 == 0, d % 64 == 0.
+template <typename T, int K>
+__global__ __launch_bounds__(256) void sru_pack_wt_kernel(const float* __restrict__ w, int n_in, int d, int C,
+                                                          T* __restrict__ out) {
+    constexpr int W = 64 * K;
+    __shared__ float tile[32][W + 1];
+    const int r0 = blockIdx.x * 32, dd0 = blockIdx.y * 64, dir = blockIdx.z;
+    const int F = n_in / C;
+    for (int idx = threadIdx.x; idx < 32 * W; idx += 256) {
+        const int row = idx / W, col = idx - row * W;
+        const int r_out = r0 + row, f = r_out / C, c = r_out - f * C;
+        tile[row][col] = w[(((int64_t)(c * F + f) * 2 + dir) * d + dd0) * K + col];
+    }
+    __syncthreads();
+    const int rr = threadIdx.x & 31;
+    for (int pair = threadIdx.x >> 5; pair < W; pair += 8) {
+        const int kk = pair / 64, ddl = pair - kk * 64;
+        Elem<T>::st(out + ((int64_t)(kk * 2 + dir) * d + dd0 + ddl) * n_in + r0 + rr, tile[rr][ddl * K + kk]);
+    }
+}
+
 template <typename T, int K>
 __global__ __launch_bounds__(256) void sru_unpack_dw_kernel(const T* __restrict__ part, int S, int n_in, int d,
                                                             int C, int accumulate, float* __restrict__ dw) {
@@ -930,6 +953,23 @@ extern "C" int sp_sru_pack_w(const float* weight, int n_in, int d, int k, int C,
     else { if (k == 3) SP_PACK(__hip_bfloat16, 3); else SP_PACK(__hip_bfloat16, 4); }
 #undef SP_PACK
     return check_launch("sru_pack_w_kernel");
+}
+
+extern "C" int sp_sru_pack_wt(const float* weight, int n_in, int d, int k, int C, int dtype, void* out,
+                              void* stream) {
+    using namespace sp;
+    int rc = pack_check("sp_sru_pack_wt", n_in, d, k, C);
+    if (rc) return rc;
+    SP_CHECK_ARG(weight && out, "sp_sru_pack_wt: null pointer");
+    SP_CHECK_ARG(dtype == SP_F32 || dtype == SP_BF16, "sp_sru_pack_wt: dtype %d", dtype);
+    SP_CHECK_ARG(n_in % 32 == 0 && d % 64 == 0, "sp_sru_pack_wt: n_in %% 32 and d %% 64 must be 0 (n_in=%d d=%d)", n_in, d);
+    hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+    const dim3 grid(n_in / 32, d / 64, 2);
+#define SP_PACKT(T, K) hipLaunchKernelGGL((sru_pack_wt_kernel<T, K>), grid, dim3(256), 0, s, weight, n_in, d, C, (T*)out)
+    if (dtype == SP_F32) { if (k == 3) SP_PACKT(float, 3); else SP_PACKT(float, 4); }
+    else { if (k == 3) SP_PACKT(__hip_bfloat16, 3); else SP_PACKT(__hip_bfloat16, 4); }
+#undef SP_PACKT
+    return check_launch("sru_pack_wt_kernel");
 }
 
 extern "C" int sp_sru_unpack_dw(const void* partials, int S, int n_in, int d, int k, int C, int dtype,

@@ -299,6 +299,23 @@ def layernorm_bwd(gy2d, x2d, mean, rstd, gamma, gres2d=None, dgamma=None, dbeta=
     return gx, dgamma, dbeta
 
 
+def gemm_nt(a, b, out=None):
+    """a [M,K] @ b[N,K]^T -> [M,N], bf16, on the hand-written MFMA kernel (sp_gemm_nt_bf16)."""
+    _need_cuda(a, "a")
+    M, K = a.shape
+    N = b.shape[0]
+    if a.dtype != torch.bfloat16 or b.dtype != torch.bfloat16 or b.shape[1] != K:
+        raise ValueError("gemm_nt: bf16 operands [M,K] and [N,K] expected")
+    if a.stride(1) != 1 or b.stride(1) != 1:
+        raise ValueError("gemm_nt: operands must be K-contiguous")
+    if out is None:
+        out = torch.empty((M, N), dtype=torch.bfloat16, device=a.device)
+    with torch.cuda.device(a.device):
+        check(lib().sp_gemm_nt_bf16(ptr(a), ptr(b), ptr(out), M, N, K, a.stride(0), b.stride(0), out.stride(0),
+                                    stream_ptr()), "sp_gemm_nt_bf16")
+    return out
+
+
 class GradSink:
     """Active inside train.train_step while every parameter's .grad is a pre-allocated, zeroed f32 view
     of the optimizer's flat gradient arena (train.FlatAdam).  The backward kernels that accumulate
@@ -368,6 +385,17 @@ def sru_pack_w(weight, d, k, C, dtype):
     return out
 
 
+def sru_pack_wt(weight, d, k, C, dtype):
+    """state_dict weight f32 [n_in, 2*d*k] -> WkT [k*2*d, n_in] in dtype (columns f*C + c): sru_pack_w's
+    result transposed, the K-contiguous B operand of gemm_nt."""
+    n_in = weight.shape[0]
+    out = torch.empty((k * 2 * d, n_in), dtype=dtype, device=weight.device)
+    with torch.cuda.device(weight.device):
+        check(lib().sp_sru_pack_wt(ptr(weight), n_in, d, k, C, _lib.dtype_code(out), ptr(out), stream_ptr()),
+              "sp_sru_pack_wt")
+    return out
+
+
 def sru_unpack_dw(partials, n_in, d, k, C, out=None):
     """split-K partials [S, n_in, k*2*d] -> f32 dweight [n_in, 2*d*k] in the state_dict layout; with
     `out` (the parameter's gradient buffer) the sum is ADDED to it."""
@@ -403,6 +431,15 @@ def _splitk_dw(xn, gU2, S):
     return torch.bmm(a, b, out_dtype=torch.float32) if _bmm_f32_out else torch.bmm(a, b)
 
 
+def _own_fwd_gemm(M, n_in, N, d, dtype):
+    """The forward projection runs on sp_gemm_nt_bf16's persistent kernel where that was measured faster
+    than the library GEMM (profiles/r01_gemm.md): bf16, output-heavy (N >= 2 n_in), enough rows for at
+    least one 192-row tile per CU and column."""
+    return (dtype == torch.bfloat16 and N % 256 == 0 and n_in % 64 == 0 and d % 64 == 0 and N >= 2 * n_in
+            and (M // 192) * (N // 256) >= 256 and M * max(n_in, N) < (1 << 30))
+
+
+
 class _SRULayerFn(torch.autograd.Function):
     """One SRU layer (net.py:61-72): LayerNorm (HIP) -> projection GEMM (library) -> recurrence (HIP),
     with a hand-ordered backward: recurrence backward, the two GEMMs (dW split-K), LayerNorm backward
@@ -419,13 +456,20 @@ class _SRULayerFn(torch.autograd.Function):
             g32, b32 = g32.view(C, n_in // C).t().reshape(-1), b32.view(C, n_in // C).t().reshape(-1)
         g32, b32 = g32.contiguous(), b32.contiguous()
         xn, mean, rstd = layernorm_fwd(x2, g32, b32, eps)
-        wk = sru_pack_w(weight.detach().float().contiguous(), d, k, C, x.dtype)
-        U = torch.mm(xn, wk)
+        w32 = weight.detach().float().contiguous()
+        own = _own_fwd_gemm(T * B, n_in, 2 * d * k, d, x.dtype)
+        if own:      # wk holds W^T [N][n_in]
+            wk = sru_pack_wt(w32, d, k, C, x.dtype)
+            U = gemm_nt(xn, wk)
+        else:        # wk holds W [n_in][N]
+            wk = sru_pack_w(w32, d, k, C, x.dtype)
+            U = torch.mm(xn, wk)
         wc32, bs32 = wc.detach().float().contiguous(), bias.detach().float().contiguous()
         xr = x2 if k == 3 else None
         h, c = sru_fwd(U, xr, wc32, bs32, mask, T, B, d, k)
         ctx.save_for_backward(x2, xn, mean, rstd, g32, wk, U, wc32, bs32, mask, c)
         ctx.dims = (T, B, d, k, n_in, C)
+        ctx.wk_transposed = own
         ctx.pdt = (ln_w.dtype, ln_b.dtype, weight.dtype, wc.dtype, bias.dtype)
         ctx.params = (ln_w, ln_b, weight, wc, bias)
         return h
@@ -444,7 +488,7 @@ class _SRULayerFn(torch.autograd.Function):
         M = T * B
         S = 4 if (M % 4 == 0 and M >= 4096) else 1
         gw = sru_unpack_dw(_splitk_dw(xn, gU2, S), n_in, d, k, C, weight.grad if direct else None)
-        gxn = torch.mm(gU2, wk.t())
+        gxn = torch.mm(gU2, wk if ctx.wk_transposed else wk.t())
         gres = gxres.view(T * B, n_in) if k == 3 else None
         ln_direct = direct and C == 1   # layer 0's vectors are stored in the reference's c*F + f order
         gx, dg, db = layernorm_bwd(gxn, x2, mean, rstd, g32, gres, ln_w.grad if ln_direct else None,

@@ -549,9 +549,32 @@ def test_sru_weight_pack_unpack(cuda, dtype, n_in, d, k, C):
     ref = ref.reshape(C, n_in // C, k, 2, d).transpose(0, 1).reshape(n_in, k * 2 * d)   # rows f*C + c
     out = ops.sru_pack_w(w.to(cuda), d, k, C, dtype)
     assert torch.equal(out.cpu(), ref.to(dtype))
+    outT = ops.sru_pack_wt(w.to(cuda), d, k, C, dtype)                    # the same matrix, transposed
+    assert outT.shape == (k * 2 * d, n_in) and torch.equal(outT.cpu(), ref.to(dtype).t())
     S = 3
     parts = torch.randn(S, n_in, k * 2 * d, generator=g).to(dtype)
     tot = parts.float().sum(0)
     back = tot.view(n_in // C, C, k, 2, d).transpose(0, 1).reshape(n_in, k, 2, d).permute(0, 2, 3, 1)
     got = ops.sru_unpack_dw(parts.to(cuda), n_in, d, k, C)
     assert torch.allclose(got.cpu(), back.reshape(n_in, -1), rtol=1e-6, atol=1e-6)
+
+
+# =============================================================================== hand-written GEMM
+@pytest.mark.parametrize("M,N,K", [(256, 128, 32), (300, 256, 96), (1000, 384, 1024), (24032, 1024, 3072),
+                                   (24032, 3072, 1024), (12345, 2048, 192), (49155, 256, 64)])
+def test_gemm_nt_bf16(cuda, M, N, K):
+    """sp_gemm_nt_bf16 against an f32 matmul of the same bf16 operands (ragged M, strided rows)."""
+    from speech_amd import ops
+    g = torch.Generator().manual_seed(M + N + K)
+    a = torch.randn(M, K, generator=g).bfloat16().to(cuda)
+    b = (torch.randn(N, K, generator=g) * 0.1).bfloat16().to(cuda)
+    out = ops.gemm_nt(a, b)
+    ref = a.float() @ b.float().t()
+    err = float((out.float() - ref).abs().max())
+    assert err <= 1e-2 * float(ref.abs().max()) + 1e-3          # bf16 output rounding
+    if M >= 300:   # operands that are row slices of wider buffers
+        aw = torch.randn(M, K + 64, generator=g).bfloat16().to(cuda)
+        out2 = ops.gemm_nt(aw[:, 32:32 + K].contiguous(), b)
+        out3 = torch.empty(M, N + 8, dtype=torch.bfloat16, device=cuda)
+        ops.gemm_nt(aw[:, 32:32 + K].contiguous(), b, out=out3[:, :N])
+        assert torch.equal(out2, out3[:, :N])

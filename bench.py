@@ -207,10 +207,11 @@ def main():
     torch.manual_seed(7 + rank)
     wav, offs, labels, lens, Lmax = synth_batch(B, N, V, args.seconds, dev, args.vocab)
     T = 1 + N // 160
+    offs_host = offs.cpu()
 
     def step(i):
         masks = data.draw_masks([T] * B)                      # host RNG, like the reference
-        spec = ops.melspec(wav, offs, masks=masks)
+        spec = ops.melspec(wav, offs, masks=masks, offsets_host=offs_host)   # a loader knows the lengths on the host
         opt.param_groups[0]["lr"] = 3e-4 * lr_lambda_linear_warmup(i + 1, 3500, 10 ** 6)
         return train_step(model, opt, spec, labels, lens, 2.0, dp, max_label_len=Lmax)
 

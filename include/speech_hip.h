@@ -188,11 +188,12 @@ int sp_block_bwd_in(const void* gz, const void* z, int64_t zsb, int64_t zsf, int
  * -- the order the conv stack hands its features over in (net.py:81-83).  sp_sru_unpack_dw: the
  * inverse for the gradient, summing S split-K partials [S][n_in][k][dir][d] of dtype into f32
  * dweight[n_in][dir][d][k] (overwritten, or added to when accumulate != 0: the caller's gradient
- * buffer).  sp_sru_pack_wt: the same weight transposed, WkT[k][dir][d][n_in] (every output row n_in
- * long): the K-contiguous B operand of sp_gemm_nt_bf16 for the forward projection; n_in % 32 == 0,
+ * buffer).  sp_sru_pack_wt: the same weight transposed, WkT[k][dir][d][n_in] with row pitch ldo elements
+ * (>= n_in): the K-contiguous B operand of sp_gemm_nt_bf16 for the forward projection; n_in % 32 == 0,
  * d % 64 == 0. */
 int sp_sru_pack_w(const float* weight, int n_in, int d, int k, int C, int dtype, void* out, void* stream);
-int sp_sru_pack_wt(const float* weight, int n_in, int d, int k, int C, int dtype, void* out, void* stream);
+int sp_sru_pack_wt(const float* weight, int n_in, int d, int k, int C, int dtype, void* out, int64_t ldo,
+                   void* stream);
 int sp_sru_unpack_dw(const void* partials, int S, int n_in, int d, int k, int C, int dtype,
                      int accumulate, float* dweight, void* stream);
 
@@ -201,19 +202,24 @@ int sp_sru_unpack_dw(const void* partials, int S, int n_in, int d, int k, int C,
  * layer input; nn.LayerNorm before the classifier).  x, y, gy, gx, gres: [M][N] of dtype
  * (SP_F32 / SP_BF16), N % 8 == 0, N <= 2048; gamma, beta, mean, rstd, dgamma, dbeta f32.
  * Backward: gx = LN'(gy) (+ gres if not NULL: the SRU highway's residual gradient);
- * dgamma / dbeta are ACCUMULATED (caller zeroes).
+ * dgamma / dbeta are ACCUMULATED (caller zeroes).  ldy: row pitch of y in elements (>= N, multiple
+ * of 8; N for a dense output) -- a pitch that is not a multiple of 1024 bytes keeps the GEMM that
+ * reads y off the L2-channel conflicts of power-of-two row strides.
  * --------------------------------------------------------------------------------------- */
 int sp_layernorm_fwd(const void* x, const float* gamma, const float* beta, int64_t M, int N, float eps,
-                     int dtype, void* y, float* mean, float* rstd, void* stream);
+                     int dtype, void* y, int64_t ldy, float* mean, float* rstd, void* stream);
 int sp_layernorm_bwd(const void* gy, const void* x, const float* mean, const float* rstd,
                      const float* gamma, const void* gres, int64_t M, int N, int dtype, void* gx,
                      float* dgamma, float* dbeta, void* stream);
 
 /* ---------------------------------------------------------------------------------------
  * bf16 GEMM, both operands K-contiguous ("NT"): C[M][N] = A[M][K] * B[N][K]^T, f32 accumulate,
- * bf16 out.  Replaces the SRU projection matmuls of net.py:61-72 (sru.SRU: U = LN(x) W and its
- * data gradient gX = gU W^T; W is kept in both layouts).  N % 128 == 0, K % 32 == 0, leading
- * dimensions in elements (multiples of 8 for A and B, of 4 for C), 16-byte aligned bases.
+ * bf16 out.  Replaces the SRU forward projection matmul of net.py:61-72 (sru.SRU: U = LN(x) W, with
+ * W^T from sp_sru_pack_wt); also correct for the data gradient gX = gU W^T.  N % 128 == 0,
+ * K % 32 == 0, leading dimensions in elements (multiples of 8 for A and B, of 4 for C), 16-byte
+ * aligned bases.  Shapes with N % 256 == 0, K % 64 == 0, ldc % 8 == 0 and at least 256 tiles of
+ * 192 x 256 run on the persistent kernel (one workgroup per CU); row pitches that are not multiples
+ * of 1 KB avoid L2-channel conflicts (measured 11 % on the forward projection).
  * --------------------------------------------------------------------------------------- */
 int sp_gemm_nt_bf16(const void* A, const void* B, void* C, int M, int N, int K, int64_t lda, int64_t ldb,
                     int64_t ldc, void* stream);

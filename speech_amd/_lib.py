@@ -43,10 +43,10 @@ SIGNATURES = {
     "sp_block_out": (_i, [_vp, _vp, _vp, _i, _i, _i, _vp, _i64, _i64, _i64, _vp]),
     "sp_block_bwd_in": (_i, [_vp, _vp, _i64, _i64, _i64, _vp, _i, _i, _i, _vp, _vp, _vp]),
     "sp_sru_pack_w": (_i, [_vp, _i, _i, _i, _i, _i, _vp, _vp]),
-    "sp_sru_pack_wt": (_i, [_vp, _i, _i, _i, _i, _i, _vp, _vp]),
+    "sp_sru_pack_wt": (_i, [_vp, _i, _i, _i, _i, _i, _vp, _i64, _vp]),
     "sp_sru_unpack_dw": (_i, [_vp, _i, _i, _i, _i, _i, _i, _i, _vp, _vp]),
     "sp_gemm_nt_bf16": (_i, [_vp, _vp, _vp, _i, _i, _i, _i64, _i64, _i64, _vp]),
-    "sp_layernorm_fwd": (_i, [_vp, _vp, _vp, _i64, _i, _f, _i, _vp, _vp, _vp, _vp]),
+    "sp_layernorm_fwd": (_i, [_vp, _vp, _vp, _i64, _i, _f, _i, _vp, _i64, _vp, _vp, _vp]),
     "sp_layernorm_bwd": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _i64, _i, _i, _vp, _vp, _vp, _vp]),
 }
 

@@ -332,6 +332,7 @@ __global__ __launch_bounds__(512, 1) void gemm_nt_persist_kernel(
 #undef SP_WAIT_FRAGS
 }
 
+
 }  // namespace sp
 
 extern "C" int sp_gemm_nt_bf16(const void* A, const void* B, void* C, int M, int N, int K, int64_t lda,
@@ -355,7 +356,6 @@ extern "C" int sp_gemm_nt_bf16(const void* A, const void* B, void* C, int M, int
             const int64_t rounds = ((t + 7) / 8 + 31) / 32;
             if (best_cost < 0 || rounds * mb < best_cost) best_cost = rounds * mb, best_mb = mb;
         }
-        if (getenv("SP_MB")) best_mb = atoi(getenv("SP_MB"));
         const int ntn = N / 256;
         const int64_t t = (int64_t)((M + 64 * best_mb - 1) / (64 * best_mb)) * ntn;
         SP_CHECK_ARG(t < ((int64_t)1 << 30), "sp_gemm_nt_bf16: too many tiles");

@@ -76,7 +76,7 @@ template <> struct Raw8<float> {
 template <typename T, int NCH>
 __global__ __launch_bounds__(256) void ln_fwd_kernel(const T* __restrict__ x, const float* __restrict__ gamma,
                                                      const float* __restrict__ beta, int64_t M, int N, float eps,
-                                                     T* __restrict__ y, float* __restrict__ mean_out,
+                                                     T* __restrict__ y, int64_t ldy, float* __restrict__ mean_out,
                                                      float* __restrict__ rstd_out) {
     const int lane = threadIdx.x & 63;
     const int nchunk = N >> 3;
@@ -122,7 +122,7 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(const T* __restrict__ x, co
                 rg.get(gm); rb.get(bt);
 #pragma unroll
                 for (int j = 0; j < 8; ++j) o[j] = (v[c][j] - mean) * rstd * gm[j] + bt[j];
-                Vec8<T>::st(y + row * N + ch * 8, o);
+                Vec8<T>::st(y + row * ldy + ch * 8, o);
             }
         }
     }
@@ -233,9 +233,10 @@ static int ln_check(const char* who, int64_t M, int N, int dtype) {
 using namespace sp;
 
 extern "C" int sp_layernorm_fwd(const void* x, const float* gamma, const float* beta, int64_t M, int N, float eps,
-                                int dtype, void* y, float* mean, float* rstd, void* stream) {
+                                int dtype, void* y, int64_t ldy, float* mean, float* rstd, void* stream) {
     int rc = ln_check("sp_layernorm_fwd", M, N, dtype);
     if (rc) return rc;
+    SP_CHECK_ARG(ldy >= N && ldy % 8 == 0, "sp_layernorm_fwd: ldy=%lld must be >= N and a multiple of 8", (long long)ldy);
     if (M == 0) return SP_OK;
     SP_CHECK_ARG(x && gamma && beta && y && mean && rstd, "sp_layernorm_fwd: null pointer");
     int64_t blocks = (M + 3) / 4;
@@ -243,7 +244,7 @@ extern "C" int sp_layernorm_fwd(const void* x, const float* gamma, const float* 
     hipStream_t s = (hipStream_t)stream;
     const int nch = (N + 511) / 512;
 #define SP_LN_FWD(T, NCH) hipLaunchKernelGGL((ln_fwd_kernel<T, NCH>), dim3((int)blocks), dim3(256), 0, s, (const T*)x, \
-                                             gamma, beta, M, N, eps, (T*)y, mean, rstd)
+                                             gamma, beta, M, N, eps, (T*)y, ldy, mean, rstd)
 #define SP_LN_FWD_T(T) { if (nch == 1) SP_LN_FWD(T, 1); else if (nch == 2) SP_LN_FWD(T, 2); \
                          else if (nch == 3) SP_LN_FWD(T, 3); else SP_LN_FWD(T, 4); }
     if (dtype == SP_F32) SP_LN_FWD_T(float) else SP_LN_FWD_T(__hip_bfloat16)

@@ -892,7 +892,7 @@ __global__ __launch_bounds__(256) void sru_pack_w_kernel(const float* __restrict
 // of one weight row, writes are 32 consecutive r_out of one output row.  Needs n_in % 32 == 0, d % 64 == 0.
 template <typename T, int K>
 __global__ __launch_bounds__(256) void sru_pack_wt_kernel(const float* __restrict__ w, int n_in, int d, int C,
-                                                          T* __restrict__ out) {
+                                                          T* __restrict__ out, int64_t ldo) {
     constexpr int W = 64 * K;
     __shared__ float tile[32][W + 1];
     const int r0 = blockIdx.x * 32, dd0 = blockIdx.y * 64, dir = blockIdx.z;
@@ -906,7 +906,7 @@ __global__ __launch_bounds__(256) void sru_pack_wt_kernel(const float* __restric
     const int rr = threadIdx.x & 31;
     for (int pair = threadIdx.x >> 5; pair < W; pair += 8) {
         const int kk = pair / 64, ddl = pair - kk * 64;
-        Elem<T>::st(out + ((int64_t)(kk * 2 + dir) * d + dd0 + ddl) * n_in + r0 + rr, tile[rr][ddl * K + kk]);
+        Elem<T>::st(out + ((int64_t)(kk * 2 + dir) * d + dd0 + ddl) * ldo + r0 + rr, tile[rr][ddl * K + kk]);
     }
 }
 
@@ -956,16 +956,17 @@ extern "C" int sp_sru_pack_w(const float* weight, int n_in, int d, int k, int C,
 }
 
 extern "C" int sp_sru_pack_wt(const float* weight, int n_in, int d, int k, int C, int dtype, void* out,
-                              void* stream) {
+                              int64_t ldo, void* stream) {
     using namespace sp;
     int rc = pack_check("sp_sru_pack_wt", n_in, d, k, C);
     if (rc) return rc;
     SP_CHECK_ARG(weight && out, "sp_sru_pack_wt: null pointer");
     SP_CHECK_ARG(dtype == SP_F32 || dtype == SP_BF16, "sp_sru_pack_wt: dtype %d", dtype);
+    SP_CHECK_ARG(ldo >= n_in, "sp_sru_pack_wt: ldo=%lld smaller than n_in=%d", (long long)ldo, n_in);
     SP_CHECK_ARG(n_in % 32 == 0 && d % 64 == 0, "sp_sru_pack_wt: n_in %% 32 and d %% 64 must be 0 (n_in=%d d=%d)", n_in, d);
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
     const dim3 grid(n_in / 32, d / 64, 2);
-#define SP_PACKT(T, K) hipLaunchKernelGGL((sru_pack_wt_kernel<T, K>), grid, dim3(256), 0, s, weight, n_in, d, C, (T*)out)
+#define SP_PACKT(T, K) hipLaunchKernelGGL((sru_pack_wt_kernel<T, K>), grid, dim3(256), 0, s, weight, n_in, d, C, (T*)out, ldo)
     if (dtype == SP_F32) { if (k == 3) SP_PACKT(float, 3); else SP_PACKT(float, 4); }
     else { if (k == 3) SP_PACKT(__hip_bfloat16, 3); else SP_PACKT(__hip_bfloat16, 4); }
 #undef SP_PACKT

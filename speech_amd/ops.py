@@ -69,13 +69,20 @@ def num_frames(n_samples):
     return 1 + n_samples // HOP
 
 
-def melspec(wav, offsets, t_max=None, masks=None, flags=0, plan=None, out=None):
+def melspec(wav, offsets, t_max=None, masks=None, flags=0, plan=None, out=None, offsets_host=None):
     """wav: flat f32 device tensor of concatenated utterances; offsets: int64 [B+1] (device or
-    host) -> mel [B, 1, 80, T_max] f32.  masks: int32 [B,4] (f0, fw, t0, tw) or None."""
+    host) -> mel [B, 1, 80, T_max] f32.  masks: int32 [B,4] (f0, fw, t0, tw) or None.
+    offsets_host: the same offsets on the host, when the caller has them (a loader does): with device
+    `offsets` alone the shapes have to be fetched back, which drains the stream once per call."""
     _need_cuda(wav, "wav")
     if wav.dtype != torch.float32 or not wav.is_contiguous():
         raise ValueError("wav must be a contiguous float32 tensor")
-    offs_host = offsets.detach().cpu().to(torch.int64) if offsets.is_cuda else offsets.to(torch.int64)
+    if offsets_host is not None:
+        offs_host = torch.as_tensor(offsets_host, dtype=torch.int64)
+        if offs_host.is_cuda or offs_host.numel() != offsets.numel():
+            raise ValueError("offsets_host must be a host copy of offsets")
+    else:
+        offs_host = offsets.detach().cpu().to(torch.int64) if offsets.is_cuda else offsets.to(torch.int64)
     B = offs_host.numel() - 1
     lens = offs_host[1:] - offs_host[:-1]
     if B > 0:
@@ -90,7 +97,9 @@ def melspec(wav, offsets, t_max=None, masks=None, flags=0, plan=None, out=None):
         raise ValueError(f"t_max={t_max} smaller than the longest utterance ({tb_max} frames)")
     offs_dev = offsets if offsets.is_cuda and offsets.dtype == torch.int64 else offs_host.to(wav.device)
     if masks is not None:
-        masks = masks.to(device=wav.device, dtype=torch.int32).contiguous()
+        if not masks.is_cuda:     # pinned staging + async copy: a pageable copy would wait for the stream
+            masks = masks.to(torch.int32).contiguous().pin_memory()
+        masks = masks.to(device=wav.device, dtype=torch.int32, non_blocking=True).contiguous()
         if tuple(masks.shape) != (B, 4):
             raise ValueError("masks must be [B, 4]")
     if plan is None:
@@ -273,14 +282,16 @@ def sru_recurrence(U, xres, wc, bias, mask, d):
 # ------------------------------------------------------------------------------------------
 # LayerNorm and the fused SRU layer (net.py:61-76)
 # ------------------------------------------------------------------------------------------
-def layernorm_fwd(x2d, gamma, beta, eps):
+def layernorm_fwd(x2d, gamma, beta, eps, pad=0):
+    """pad: extra elements per output row (multiple of 8): y is then an [M, N] view of an [M, N + pad]
+    buffer (see sp_layernorm_fwd's ldy)."""
     M, N = x2d.shape
-    y = torch.empty_like(x2d)
+    y = torch.empty((M, N + pad), dtype=x2d.dtype, device=x2d.device)[:, :N] if pad else torch.empty_like(x2d)
     mean = torch.empty(M, dtype=torch.float32, device=x2d.device)
     rstd = torch.empty(M, dtype=torch.float32, device=x2d.device)
     with torch.cuda.device(x2d.device):
         check(lib().sp_layernorm_fwd(ptr(x2d), ptr(gamma), ptr(beta), M, N, float(eps), _lib.dtype_code(x2d),
-                                     ptr(y), ptr(mean), ptr(rstd), stream_ptr()), "sp_layernorm_fwd")
+                                     ptr(y), y.stride(0), ptr(mean), ptr(rstd), stream_ptr()), "sp_layernorm_fwd")
     return y, mean, rstd
 
 
@@ -385,14 +396,14 @@ def sru_pack_w(weight, d, k, C, dtype):
     return out
 
 
-def sru_pack_wt(weight, d, k, C, dtype):
+def sru_pack_wt(weight, d, k, C, dtype, pad=0):
     """state_dict weight f32 [n_in, 2*d*k] -> WkT [k*2*d, n_in] in dtype (columns f*C + c): sru_pack_w's
-    result transposed, the K-contiguous B operand of gemm_nt."""
+    result transposed, the K-contiguous B operand of gemm_nt; pad: extra elements per row of the buffer."""
     n_in = weight.shape[0]
-    out = torch.empty((k * 2 * d, n_in), dtype=dtype, device=weight.device)
+    out = torch.empty((k * 2 * d, n_in + pad), dtype=dtype, device=weight.device)[:, :n_in]
     with torch.cuda.device(weight.device):
-        check(lib().sp_sru_pack_wt(ptr(weight), n_in, d, k, C, _lib.dtype_code(out), ptr(out), stream_ptr()),
-              "sp_sru_pack_wt")
+        check(lib().sp_sru_pack_wt(ptr(weight), n_in, d, k, C, _lib.dtype_code(out), ptr(out), out.stride(0),
+                                   stream_ptr()), "sp_sru_pack_wt")
     return out
 
 
@@ -455,11 +466,13 @@ class _SRULayerFn(torch.autograd.Function):
         if C > 1:
             g32, b32 = g32.view(C, n_in // C).t().reshape(-1), b32.view(C, n_in // C).t().reshape(-1)
         g32, b32 = g32.contiguous(), b32.contiguous()
-        xn, mean, rstd = layernorm_fwd(x2, g32, b32, eps)
-        w32 = weight.detach().float().contiguous()
         own = _own_fwd_gemm(T * B, n_in, 2 * d * k, d, x.dtype)
+        # rows whose pitch is a multiple of 1 KB land on few L2 channels when 256 CUs walk them in step
+        pad = 64 if own and (n_in * x.element_size()) % 1024 == 0 else 0
+        xn, mean, rstd = layernorm_fwd(x2, g32, b32, eps, pad)
+        w32 = weight.detach().float().contiguous()
         if own:      # wk holds W^T [N][n_in]
-            wk = sru_pack_wt(w32, d, k, C, x.dtype)
+            wk = sru_pack_wt(w32, d, k, C, x.dtype, pad)
             U = gemm_nt(xn, wk)
         else:        # wk holds W [n_in][N]
             wk = sru_pack_w(w32, d, k, C, x.dtype)

@@ -120,12 +120,15 @@ int sp_sru_bwd(const void* U, const void* xres, const float* wc, const float* bi
 /* ---------------------------------------------------------------------------------------
  * Optimizer step over a flat fp32 arena.  Replaces train.py:81-85 (clip_grad_norm_ over all
  * parameters, then bitsandbytes Adam8bit.step()).
- * sp_sumsq_f32: out[0] = sum x_i^2 (out is zeroed on the stream first).
+ * sp_sumsq_f32: out[0] = sum x_i^2; out must hold SP_SUMSQ_WORDS floats (out[1..] are per-workgroup
+ * partials, summed in a fixed order: the result is bit-reproducible, so data-parallel replicas that
+ * hold the same reduced gradient derive the same clip coefficient and stay identical).
  * sp_adam_step_f32: bias-corrected Adam, step >= 1.  Gradient used = g * clip / grad_div where
  * clip = min(1, max_norm / (sqrt(sumsq[0]) + 1e-6)) if sumsq != NULL and max_norm > 0, else 1
  * (clip_grad_norm_ semantics, no host sync).  decoupled != 0: p *= 1 - lr*wd after the update
  * (bitsandbytes kernels); 0: g += wd * p (L2).
  * --------------------------------------------------------------------------------------- */
+#define SP_SUMSQ_WORDS 1025
 int sp_sumsq_f32(const float* x, int64_t n, float* out, void* stream);
 int sp_adam_step_f32(float* p, const float* g, float* m, float* v, int64_t n, float lr, float beta1,
                      float beta2, float eps, float weight_decay, int step, int decoupled,

@@ -27,7 +27,19 @@ __global__ __launch_bounds__(256) void sumsq_kernel(const float* __restrict__ x,
     __shared__ float s_part[4];
     if ((threadIdx.x & 63) == 0) s_part[threadIdx.x >> 6] = acc;
     __syncthreads();
-    if (threadIdx.x == 0) atomicAdd(out, s_part[0] + s_part[1] + s_part[2] + s_part[3]);
+    // one partial per workgroup, summed in a fixed order by sumsq_final_kernel: no float atomics, so
+    // every data-parallel replica derives the same clip coefficient from the same reduced gradient
+    if (threadIdx.x == 0) out[1 + blockIdx.x] = s_part[0] + s_part[1] + s_part[2] + s_part[3];
+}
+
+__global__ __launch_bounds__(256) void sumsq_final_kernel(float* __restrict__ out, int nparts) {
+    float acc = 0.f;
+    for (int i = threadIdx.x; i < nparts; i += 256) acc += out[1 + i];
+    acc = wave_sum(acc);
+    __shared__ float s_part[4];
+    if ((threadIdx.x & 63) == 0) s_part[threadIdx.x >> 6] = acc;
+    __syncthreads();
+    if (threadIdx.x == 0) out[0] = s_part[0] + s_part[1] + s_part[2] + s_part[3];
 }
 
 struct AdamArgs {
@@ -87,13 +99,11 @@ extern "C" int sp_sumsq_f32(const float* x, int64_t n, float* out, void* stream)
     SP_CHECK_ARG(n >= 0 && out, "sp_sumsq_f32: bad arguments");
     SP_CHECK_ARG(((uintptr_t)x & 15) == 0, "sp_sumsq_f32: x must be 16-byte aligned");
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
-    hipError_t e = hipMemsetAsync(out, 0, sizeof(float), s);
-    if (e != hipSuccess) return fail(SP_ELAUNCH, "sp_sumsq_f32: %s", hipGetErrorString(e));
-    if (n == 0) return SP_OK;
     int64_t blocks = (n / 4 + 255) / 256;
-    if (blocks > 2048) blocks = 2048;
+    if (blocks > SP_SUMSQ_WORDS - 1) blocks = SP_SUMSQ_WORDS - 1;
     if (blocks < 1) blocks = 1;
     hipLaunchKernelGGL(sumsq_kernel, dim3((int)blocks), dim3(256), 0, s, x, n, out);
+    hipLaunchKernelGGL(sumsq_final_kernel, dim3(1), dim3(256), 0, s, out, (int)blocks);
     return check_launch("sumsq_kernel");
 }
 

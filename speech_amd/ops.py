@@ -442,6 +442,9 @@ def _splitk_dw(xn, gU2, S):
     return torch.bmm(a, b, out_dtype=torch.float32) if _bmm_f32_out else torch.bmm(a, b)
 
 
+import os as _os
+
+
 def _own_fwd_gemm(M, n_in, N, d, dtype):
     """The forward projection runs on sp_gemm_nt_bf16's persistent kernel where that was measured faster
     than the library GEMM (profiles/r01_gemm.md): bf16, output-heavy (N >= 2 n_in), enough rows for at
@@ -469,6 +472,8 @@ class _SRULayerFn(torch.autograd.Function):
         own = _own_fwd_gemm(T * B, n_in, 2 * d * k, d, x.dtype)
         # rows whose pitch is a multiple of 1 KB land on few L2 channels when 256 CUs walk them in step
         pad = 64 if own and (n_in * x.element_size()) % 1024 == 0 else 0
+        if _os.environ.get('SP_NOPAD'): pad = 0
+        if _os.environ.get('SP_NOOWN'): own = False; pad = 0
         xn, mean, rstd = layernorm_fwd(x2, g32, b32, eps, pad)
         w32 = weight.detach().float().contiguous()
         if own:      # wk holds W^T [N][n_in]

@@ -24,7 +24,7 @@ import torch
 import torch.distributed as dist
 
 from . import data, decoder, net, ops
-from ._lib import check, lib, ptr, stream_ptr
+from ._lib import SUMSQ_WORDS, check, lib, ptr, stream_ptr
 
 
 def lr_lambda_linear_warmup(current_step, num_warmup_steps, num_training_steps):
@@ -73,7 +73,7 @@ class FlatAdam(torch.optim.Optimizer):
         self.flat_grad = torch.zeros(total, dtype=torch.float32, device=dev)
         self.exp_avg = torch.zeros(total, dtype=torch.float32, device=dev)
         self.exp_avg_sq = torch.zeros(total, dtype=torch.float32, device=dev)
-        self.sumsq = torch.zeros(1, dtype=torch.float32, device=dev)
+        self.sumsq = torch.zeros(SUMSQ_WORDS, dtype=torch.float32, device=dev)   # [0] = sum, rest partials
         for p, off in zip(params, self.offsets):
             n = p.numel()
             self.flat[off:off + n].copy_(p.data.reshape(-1).float())

@@ -1,0 +1,98 @@
+"""GPU test of the data-parallel training step: two ranks that share the one card, gradient exchange
+over gloo (RCCL refuses two ranks on one device; the exchange logic, the stream ordering between the
+backward kernels and the asynchronous bucket all-reduces, and the GradSink reports are the same code
+as under RCCL).  Both replicas must hold identical parameters after every step, and those must match
+a single-process step on the concatenated batch gradients."""
+import os
+import socket
+
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+pytestmark = pytest.mark.gpu
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _model(dev):
+    from speech_amd import net
+    torch.manual_seed(0)
+    m = net.SRModel(2, 64, 28, 80, 0.0, 0, compute_dtype=torch.float32).to(dev)
+    with torch.no_grad():
+        for blk in m.resnet_layers:
+            blk.bn2.weight.uniform_(0.5, 1.0)
+    return m.train()
+
+
+def _batch(rank, dev):
+    g = torch.Generator().manual_seed(10 + rank)
+    spec = (torch.rand(3, 1, 80, 101, generator=g) * 3).to(dev)
+    labels = torch.randint(1, 29, (3, 12), generator=g).to(dev)
+    lens = torch.tensor([12, 7, 9], dtype=torch.int32, device=dev)
+    return spec, labels, lens
+
+
+def _worker(rank, world, port, out):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    torch.cuda.set_device(0)
+    dev = torch.device("cuda", 0)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from speech_amd.train import BucketedAllReduce, FlatAdam, train_step
+    m = _model(dev)
+    if rank == 1:   # the initial broadcast must repair this
+        with torch.no_grad():
+            for p in m.parameters():
+                p.add_(0.5)
+    opt = FlatAdam(m.parameters(), lr=1e-3, weight_decay=1e-3)
+    dp = BucketedAllReduce(opt, bucket_mb=0.25)
+    spec, labels, lens = _batch(rank, dev)
+    losses, grads, step0 = [], [], opt.step
+
+    def step(**kw):                       # the reduced gradient as the optimizer sees it
+        grads.append(opt.flat_grad.detach().cpu().clone())
+        return step0(**kw)
+    opt.step = step
+    for _ in range(2):
+        losses.append(float(train_step(m, opt, spec, labels, lens, 2.0, dp, max_label_len=12)))
+    torch.cuda.synchronize()
+    torch.save({"flat": opt.flat.detach().cpu(), "losses": losses, "nbuckets": len(dp.buckets), "grad0": grads[0]},
+               os.path.join(out, f"rank{rank}.pt"))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_two_rank_train_step_on_one_gpu(cuda, tmp_path):
+    world, port = 2, _free_port()
+    mp.spawn(_worker, args=(world, port, str(tmp_path)), nprocs=world, join=True)
+    r0 = torch.load(tmp_path / "rank0.pt", weights_only=True)
+    r1 = torch.load(tmp_path / "rank1.pt", weights_only=True)
+    assert r0["nbuckets"] >= 2
+    assert all(torch.isfinite(torch.tensor(r["losses"])).all() for r in (r0, r1))
+    assert torch.equal(r0["flat"], r1["flat"])                     # replicas stay bit-identical
+    assert torch.equal(r0["grad0"], r1["grad0"])
+    # single process: the first step's gradient is the sum of the two batches' gradients
+    from speech_amd import ops
+    from speech_amd.train import FlatAdam
+    m = _model(cuda)
+    opt = FlatAdam(m.parameters(), lr=1e-3, weight_decay=1e-3)
+    opt.zero_grad()
+    for rank in range(2):
+        spec, labels, lens = _batch(rank, cuda)
+        out = m(spec)
+        il = torch.full((3,), out.shape[1], dtype=torch.int32, device=cuda)
+        ops.ctc_loss(out.float(), labels, il, lens, blank=0, max_label_len=12).backward()
+    ref = opt.flat_grad.detach().cpu()
+    # the conv stack accumulates activation gradients with bf16 atomics (order-dependent rounding,
+    # ~1e-3 of the range observed); a missed or doubled reduction would be off by O(1)
+    assert float((r0["grad0"] - ref).abs().max()) <= 2e-2 * float(ref.abs().max())
+    # and it is the SUM, not the mean or one rank's share
+    assert float((r0["grad0"] - 2 * ref / 2).abs().max()) < float((r0["grad0"] - ref / 2).abs().max())

@@ -146,14 +146,17 @@ int sp_adam_step_f32(float* p, const float* g, float* m, float* v, int64_t n, fl
  *   c[64:96] (BatchNorm backward from (dz, y)).  Zero padding applies after tf.  epi_mode 0: none
  *   (forward, bias added); 1: out *= [e[0:32]*epi_src + e[32:64] > 0] (ReLU mask recomputed from
  *   the pre-BN tensor); 2: out += epi_src (residual gradient).  Supported pairs: (0,0) (1,0) (2,1) (2,2).
- *   bn_sums (may be NULL; zeroed inside): the BatchNorm reduction over the OUTPUT fused into the
- *   epilogue -- epi_mode 0: what sp_bn_stats(out) gives; epi_mode 1: what sp_bn_bwd_reduce(out, epi_src) gives.
+ *   bn_sums (may be NULL): the BatchNorm reduction over the OUTPUT fused into the epilogue --
+ *   epi_mode 0: what sp_bn_stats(out) gives; epi_mode 1: what sp_bn_bwd_reduce(out, epi_src) gives.
+ *   Every `sums` / `bn_sums` buffer holds SP_BN_SUMS_WORDS floats: [0:64] the result, the rest one
+ *   64-float partial per workgroup of the producing launch, summed in a fixed order (no float
+ *   atomics): statistics, and with them every bf16 activation, are bit-reproducible.
  * sp_conv3x5_wgrad: gw[32][32][3][5] += sum_pos dy[pos][co] * a[pos + tap][ci], with
  *   a = a_src (a_mode 0) or relu(BN(a_src)) (a_mode 1), dy = g_coef affine of (g, y) as in_mode 2.
  *   gwp_ws: 8*15*32*32 f32 scratch (zeroed inside; one partial copy per XCD).
  * sp_conv_stem_fwd/bwd: Conv2d(1,32,3,stride 2,pad 1) on the f32 spectrogram [B][Fin][Tin] ->
  *   [B][F][T][32], F = (Fin-1)/2+1, T = (Tin-1)/2+1; bwd accumulates gw[32*9], gbias[32].
- * sp_bn_stats: sums[0:32] = sum y, sums[32:64] = sum y^2 (zeroed inside).
+ * sp_bn_stats: sums[0:32] = sum y, sums[32:64] = sum y^2.
  * sp_bn_bwd_reduce: sums = (sum g, sum g*y).
  * sp_bn_finalize_fwd: coef = (scale, shift), save = (mean, invstd); training != 0 uses the batch
  *   sums and updates running stats (momentum, unbiased variance), else uses running stats.
@@ -162,6 +165,7 @@ int sp_adam_step_f32(float* p, const float* g, float* m, float* v, int64_t n, fl
  *   which lets the last block write the [T][B][F*32] layout the SRU stack reads.
  * sp_block_bwd_in: gpre = gz * [z > 0] (gz, z in that layout); sums = (sum gpre, sum gpre*y2).
  * --------------------------------------------------------------------------------------- */
+#define SP_BN_SUMS_WORDS (64 + 1024 * 64)
 int sp_conv_pack_w(const float* w, int bwd_data, void* wpack, void* stream);
 int sp_conv3x5(const void* in, const void* in2, const float* coef, int in_mode, const void* wpack,
                const float* bias, const void* epi_src, const float* epi_coef, int epi_mode, int B,

@@ -10,7 +10,7 @@ BatchNorm-backward affine map the same way.
 """
 import torch
 
-from ._lib import check, lib, ptr, stream_ptr
+from ._lib import BN_SUMS_WORDS, check, lib, ptr, stream_ptr
 
 IN_ID, IN_BNRELU, IN_BNBWD = 0, 1, 2
 EPI_NONE, EPI_MASK, EPI_ADD = 0, 1, 2
@@ -29,7 +29,7 @@ def _pack(w, bwd_data):
 
 
 def _conv(inp, in2, coef, in_mode, wpack, bias, epi_src, epi_coef, epi_mode, B, F, T, bn_sums=None):
-    """bn_sums: optional f32 [64] receiving the BatchNorm reduction over the output (fused epilogue)."""
+    """bn_sums: optional f32 [BN_SUMS_WORDS] (result in [0:64]) receiving the BatchNorm reduction over the output (fused epilogue)."""
     out = torch.empty((B, F, T, C), dtype=torch.bfloat16, device=inp.device)
     check(lib().sp_conv3x5(ptr(inp), ptr(in2), ptr(coef), in_mode, ptr(wpack), ptr(bias), ptr(epi_src),
                            ptr(epi_coef), epi_mode, B, F, T, ptr(out), ptr(bn_sums), stream_ptr()), "sp_conv3x5")
@@ -69,8 +69,8 @@ class _ConvStackFn(torch.autograd.Function):
             for i in range(nblk):
                 c1w, c1b, b1w, b1b, c2w, c2b, b2w, b2b = [_f32(p) for p in params[8 * i: 8 * i + 8]]
                 rm1, rv1, rm2, rv2 = bufs[4 * i: 4 * i + 4]
-                s1 = torch.empty(64, dtype=torch.float32, device=dev) if training else None
-                s2 = torch.empty(64, dtype=torch.float32, device=dev) if training else None
+                s1 = torch.empty(BN_SUMS_WORDS, dtype=torch.float32, device=dev) if training else None
+                s2 = torch.empty(BN_SUMS_WORDS, dtype=torch.float32, device=dev) if training else None
                 y1 = _conv(x, None, None, IN_ID, _pack(c1w, 0), c1b, None, None, EPI_NONE, B, F, T, s1)
                 coef1, save1 = _bn_fwd(s1, npos, b1w, b1b, rm1, rv1, momentum, eps, training)
                 y2 = _conv(y1, None, coef1, IN_BNRELU, _pack(c2w, 0), c2b, None, None, EPI_NONE, B, F, T, s2)
@@ -120,7 +120,7 @@ class _ConvStackFn(torch.autograd.Function):
                     small = torch.zeros(6, 32, dtype=torch.float32, device=dev)
                     gg1, gb1, gg2, gb2, zb1, zb2 = small.unbind(0)
                     gw1, gw2 = torch.zeros_like(c1w), torch.zeros_like(c2w)
-                sums = torch.empty(64, dtype=torch.float32, device=dev)
+                sums = torch.empty(BN_SUMS_WORDS, dtype=torch.float32, device=dev)
                 c3_2 = torch.empty(96, dtype=torch.float32, device=dev)
                 c3_1 = torch.empty(96, dtype=torch.float32, device=dev)
                 g2pre = torch.empty((B, F, T, C), dtype=torch.bfloat16, device=dev)

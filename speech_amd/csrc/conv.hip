@@ -290,7 +290,7 @@ __global__ __launch_bounds__(256, 2) void conv3x5_kernel(
         }
         __syncthreads();                 // nobody reads this tile's strip any more
     }
-    if (stats) {   // workgroup reduction over the threads that share a channel group, 64 atomics per workgroup
+    if (stats) {   // workgroup reduction over the threads that share a channel group, one 64-float partial per workgroup
         float a16[16];
 #pragma unroll
         for (int k = 0; k < 16; ++k) a16[k] = kStatRegs ? rs[k] : sstat[k][tid];
@@ -306,7 +306,7 @@ __global__ __launch_bounds__(256, 2) void conv3x5_kernel(
             const int c4 = tid >> 4, k = tid & 15;
             const float sm = red[(0 * 4 + c4) * 16 + k] + red[(1 * 4 + c4) * 16 + k] + red[(2 * 4 + c4) * 16 + k] +
                              red[(3 * 4 + c4) * 16 + k];
-            atomicAdd(bn_sums + (k >> 3) * 32 + c4 * 8 + (k & 7), sm);
+            bn_sums[64 + blockIdx.x * 64 + (k >> 3) * 32 + c4 * 8 + (k & 7)] = sm;   // partial; see bn_sum_parts_kernel
         }
     }
 }
@@ -590,8 +590,8 @@ __global__ __launch_bounds__(256) void bn_reduce_kernel(const __hip_bfloat16* __
     float acc[16];
 #pragma unroll
     for (int i = 0; i < 16; ++i) acc[i] = 0.f;
-    // four independent 16-byte loads in flight per thread; the grid is small (reduce_blocks) because
-    // every block ends in 64 same-address atomics
+    // four independent 16-byte loads in flight per thread; the grid is small (reduce_blocks): every
+    // block ends in one 64-float partial
     const int64_t stride = (int64_t)gridDim.x * 256, total = n * 4;
     for (int64_t c0 = (int64_t)blockIdx.x * 256 + threadIdx.x; c0 < total; c0 += 4 * stride) {
         uint4 ra[4], rb[4];
@@ -627,8 +627,26 @@ __global__ __launch_bounds__(256) void bn_reduce_kernel(const __hip_bfloat16* __
     if (threadIdx.x < 64) {
         const int c4 = threadIdx.x >> 4, k = threadIdx.x & 15;
         const float s = red[0][c4][k] + red[1][c4][k] + red[2][c4][k] + red[3][c4][k];
-        atomicAdd(sums + (k >> 3) * 32 + c4 * 8 + (k & 7), s);
+        sums[64 + blockIdx.x * 64 + (k >> 3) * 32 + c4 * 8 + (k & 7)] = s;
     }
+}
+
+// sums[0..63] = sum over the producing launch's workgroups of their partials sums[64 + 64 b ..], in a
+// FIXED order (no float atomics): the BatchNorm statistics, and through them every bf16 activation of
+// the stack, are bit-reproducible from run to run and identical on data-parallel replicas.
+__global__ __launch_bounds__(256) void bn_sum_parts_kernel(float* __restrict__ sums, int nparts) {
+    __shared__ float quarter[4][64];
+    const int idx = threadIdx.x & 63, q = threadIdx.x >> 6;
+    float a0 = 0.f, a1 = 0.f;
+    int b = q;
+    for (; b + 4 < nparts; b += 8) {
+        a0 += sums[64 + b * 64 + idx];
+        a1 += sums[64 + (b + 4) * 64 + idx];
+    }
+    if (b < nparts) a0 += sums[64 + b * 64 + idx];
+    quarter[q][idx] = a0 + a1;
+    __syncthreads();
+    if (threadIdx.x < 64) sums[idx] = (quarter[0][idx] + quarter[1][idx]) + (quarter[2][idx] + quarter[3][idx]);
 }
 
 // coef[0..31] = scale, coef[32..63] = shift; save[0..31] = mean, save[32..63] = invstd
@@ -763,11 +781,11 @@ __global__ __launch_bounds__(256) void block_bwd_in_kernel(const __hip_bfloat16*
     if (threadIdx.x < 64) {
         const int c4 = threadIdx.x >> 4, k = threadIdx.x & 15;
         const float sm = red[0][c4][k] + red[1][c4][k] + red[2][c4][k] + red[3][c4][k];
-        atomicAdd(sums + (k >> 3) * 32 + c4 * 8 + (k & 7), sm);
+        sums[64 + blockIdx.x * 64 + (k >> 3) * 32 + c4 * 8 + (k & 7)] = sm;
     }
 }
 
-// grid of the reducing kernels: every block ends in 64 same-address atomics, so few and fat blocks
+// grid of the reducing kernels: every block ends in one 64-float partial, so few and fat blocks
 static int reduce_blocks(int64_t chunks) {
     int64_t b = (chunks + 1023) / 1024;
     if (b > 1024) b = 1024;
@@ -813,10 +831,6 @@ extern "C" int sp_conv3x5(const void* in, const void* in2, const float* coef, in
     dim3 grid((unsigned)(ntiles < 512 ? ntiles : 512)), blk(256);   // persistent: 2 workgroups per CU
     hipStream_t s = (hipStream_t)stream;
     SP_CHECK_ARG(!bn_sums || epi_mode != EPI_ADD, "sp_conv3x5: fused statistics exist for epi_mode 0 and 1");
-    if (bn_sums) {
-        hipError_t e = hipMemsetAsync(bn_sums, 0, 64 * sizeof(float), s);
-        if (e != hipSuccess) return fail(SP_ELAUNCH, "sp_conv3x5: %s", hipGetErrorString(e));
-    }
 #define SP_CONV_LAUNCH(IM, EP)                                                                          \
     hipLaunchKernelGGL((conv3x5_kernel<IM, EP>), grid, blk, 0, s, (const bf16*)in, (const bf16*)in2, coef, \
                        (const bf16*)wpack, bias, (const bf16*)epi_src, epi_coef, B, F, T, (bf16*)out, bn_sums)
@@ -826,6 +840,7 @@ extern "C" int sp_conv3x5(const void* in, const void* in2, const float* coef, in
     else if (in_mode == IN_BNBWD && epi_mode == EPI_ADD) SP_CONV_LAUNCH(IN_BNBWD, EPI_ADD);
     else return fail(SP_EINVAL, "sp_conv3x5: unsupported mode pair (%d, %d)", in_mode, epi_mode);
 #undef SP_CONV_LAUNCH
+    if (bn_sums) hipLaunchKernelGGL(bn_sum_parts_kernel, dim3(1), dim3(256), 0, s, bn_sums, (int)grid.x);
     return check_launch("conv3x5_kernel");
 }
 
@@ -878,20 +893,20 @@ extern "C" int sp_conv_stem_bwd(const float* spec, const void* gout, int B, int 
 extern "C" int sp_bn_stats(const void* y, int64_t npos, float* sums, void* stream) {
     SP_CHECK_ARG(y && sums && npos >= 1, "sp_bn_stats: bad arguments");
     hipStream_t s = (hipStream_t)stream;
-    hipError_t e = hipMemsetAsync(sums, 0, 64 * sizeof(float), s);
-    if (e != hipSuccess) return fail(SP_ELAUNCH, "sp_bn_stats: %s", hipGetErrorString(e));
-    hipLaunchKernelGGL((bn_reduce_kernel<0>), dim3(reduce_blocks(npos * 4)), dim3(256), 0, s, (const bf16*)y,
+    const int nb = reduce_blocks(npos * 4);
+    hipLaunchKernelGGL((bn_reduce_kernel<0>), dim3(nb), dim3(256), 0, s, (const bf16*)y,
                        (const bf16*)nullptr, npos, sums);
+    hipLaunchKernelGGL(bn_sum_parts_kernel, dim3(1), dim3(256), 0, s, sums, nb);
     return check_launch("bn_reduce_kernel<0>");
 }
 
 extern "C" int sp_bn_bwd_reduce(const void* g, const void* y, int64_t npos, float* sums, void* stream) {
     SP_CHECK_ARG(g && y && sums && npos >= 1, "sp_bn_bwd_reduce: bad arguments");
     hipStream_t s = (hipStream_t)stream;
-    hipError_t e = hipMemsetAsync(sums, 0, 64 * sizeof(float), s);
-    if (e != hipSuccess) return fail(SP_ELAUNCH, "sp_bn_bwd_reduce: %s", hipGetErrorString(e));
-    hipLaunchKernelGGL((bn_reduce_kernel<1>), dim3(reduce_blocks(npos * 4)), dim3(256), 0, s, (const bf16*)g,
+    const int nb = reduce_blocks(npos * 4);
+    hipLaunchKernelGGL((bn_reduce_kernel<1>), dim3(nb), dim3(256), 0, s, (const bf16*)g,
                        (const bf16*)y, npos, sums);
+    hipLaunchKernelGGL(bn_sum_parts_kernel, dim3(1), dim3(256), 0, s, sums, nb);
     return check_launch("bn_reduce_kernel<1>");
 }
 
@@ -932,8 +947,6 @@ extern "C" int sp_block_bwd_in(const void* gz, const void* z, int64_t zsb, int64
     SP_CHECK_ARG(gz && z && y2 && gpre && sums, "sp_block_bwd_in: null pointer");
     SP_CHECK_ARG(zsb % 8 == 0 && zsf % 8 == 0 && zst % 8 == 0, "sp_block_bwd_in: strides must keep 16-byte chunks aligned");
     hipStream_t s = (hipStream_t)stream;
-    hipError_t e = hipMemsetAsync(sums, 0, 64 * sizeof(float), s);
-    if (e != hipSuccess) return fail(SP_ELAUNCH, "sp_block_bwd_in: %s", hipGetErrorString(e));
     Strides zs{zsb, zsf, zst};
     SP_CHECK_ARG((int64_t)B * F * T * 4 < ((int64_t)1 << 31), "sp_block_bwd_in: too many positions");
     const bool dense = zst == 32 && zsf == (int64_t)T * 32 && zsb == (int64_t)F * T * 32;
@@ -944,5 +957,6 @@ extern "C" int sp_block_bwd_in(const void* gz, const void* z, int64_t zsb, int64
     else
         hipLaunchKernelGGL((block_bwd_in_kernel<false>), dim3(nb), dim3(256), 0, s, (const bf16*)gz, (const bf16*)z, zs,
                            (const bf16*)y2, B, F, T, (bf16*)gpre, sums);
+    hipLaunchKernelGGL(bn_sum_parts_kernel, dim3(1), dim3(256), 0, s, sums, nb);
     return check_launch("block_bwd_in_kernel");
 }

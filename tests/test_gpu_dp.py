@@ -91,8 +91,6 @@ def test_two_rank_train_step_on_one_gpu(cuda, tmp_path):
         il = torch.full((3,), out.shape[1], dtype=torch.int32, device=cuda)
         ops.ctc_loss(out.float(), labels, il, lens, blank=0, max_label_len=12).backward()
     ref = opt.flat_grad.detach().cpu()
-    # the conv stack accumulates activation gradients with bf16 atomics (order-dependent rounding,
-    # ~1e-3 of the range observed); a missed or doubled reduction would be off by O(1)
-    assert float((r0["grad0"] - ref).abs().max()) <= 2e-2 * float(ref.abs().max())
-    # and it is the SUM, not the mean or one rank's share
-    assert float((r0["grad0"] - 2 * ref / 2).abs().max()) < float((r0["grad0"] - ref / 2).abs().max())
+    # the forward is bit-reproducible; the weight-gradient kernels add with f32 atomics (order-dependent
+    # last bits) and the all-reduce adds the two ranks in another order than one process does
+    assert float((r0["grad0"] - ref).abs().max()) <= 1e-4 * float(ref.abs().max())

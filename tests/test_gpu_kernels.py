@@ -447,7 +447,9 @@ def test_conv_kernels_individually(cuda, shape):
                                      ptr(ws), ptr(gw), stream_ptr()), "wgrad")
         assert _relmax(gw, ref_gw) <= 2e-3, mode
     # --- BN backward reduce / block backward entry
-    sums = torch.empty(64, device=cuda)
+    from speech_amd._lib import BN_SUMS_WORDS
+    sums_buf = torch.empty(BN_SUMS_WORDS, device=cuda)
+    sums = sums_buf[:64]
     check(lib().sp_bn_bwd_reduce(ptr(gten), ptr(yten), B * Fq * T, ptr(sums), stream_ptr()), "reduce")
     ref_s = torch.cat([gten.float().sum((0, 1, 2)), (gten.float() * yten.float()).sum((0, 1, 2))])
     assert float((sums - ref_s).abs().max()) <= 2e-3 * float(ref_s.abs().max()) + 1e-2
@@ -557,6 +559,28 @@ def test_sru_weight_pack_unpack(cuda, dtype, n_in, d, k, C):
     back = tot.view(n_in // C, C, k, 2, d).transpose(0, 1).reshape(n_in, k, 2, d).permute(0, 2, 3, 1)
     got = ops.sru_unpack_dw(parts.to(cuda), n_in, d, k, C)
     assert torch.allclose(got.cpu(), back.reshape(n_in, -1), rtol=1e-6, atol=1e-6)
+
+
+def test_conv_fused_bn_sums_are_reproducible(cuda):
+    """The statistics fused into the convolution epilogue equal sp_bn_stats of its output, and two
+    launches give the same BITS (per-workgroup partials summed in a fixed order, no float atomics)."""
+    from speech_amd import convstack as cs
+    from speech_amd._lib import BN_SUMS_WORDS, check, lib, ptr, stream_ptr
+    g = torch.Generator().manual_seed(5)
+    B, F, T = 3, 40, 333
+    x = torch.randn(B, F, T, 32, generator=g).bfloat16().to(cuda)
+    w = (torch.randn(32, 32, 3, 5, generator=g) * 0.1).to(cuda)
+    bias = torch.randn(32, generator=g).to(cuda)
+    s1 = torch.empty(BN_SUMS_WORDS, device=cuda)
+    s2 = torch.full((BN_SUMS_WORDS,), float("nan"), device=cuda)     # nothing relies on a zeroed buffer
+    y1 = cs._conv(x, None, None, cs.IN_ID, cs._pack(w, 0), bias, None, None, cs.EPI_NONE, B, F, T, s1)
+    y2 = cs._conv(x, None, None, cs.IN_ID, cs._pack(w, 0), bias, None, None, cs.EPI_NONE, B, F, T, s2)
+    assert torch.equal(y1, y2) and torch.equal(s1[:64], s2[:64])
+    s3 = torch.empty(BN_SUMS_WORDS, device=cuda)
+    check(lib().sp_bn_stats(ptr(y1), B * F * T, ptr(s3), stream_ptr()), "sp_bn_stats")
+    ref = torch.cat([y1.float().reshape(-1, 32).sum(0), y1.float().reshape(-1, 32).pow(2).sum(0)])
+    assert torch.allclose(s1[:64], ref, rtol=1e-4, atol=1e-2)
+    assert torch.allclose(s3[:64], ref, rtol=1e-4, atol=1e-2)
 
 
 # =============================================================================== hand-written GEMM

@@ -235,9 +235,9 @@ def test_grad_sink_matches_autograd_accumulation(cuda):
     run(m2, ops.GradSink(_DP()))
     for (k, p1), (_, p2) in zip(m1.named_parameters(), m2.named_parameters()):
         g1 = p1.grad if p1.grad is not None else torch.zeros_like(p1)
-        # two bf16 runs differ by atomics' summation order (BN statistics -> ReLU mask flips): the test
-        # is about wiring -- every gradient in its own slot, reported once -- not about rounding
-        tol = 8e-2 * float(g1.abs().max()) + 1e-6
+        # forward and activation gradients are bit-reproducible; the two paths differ by the order of
+        # f32 additions only (atomics in the weight-gradient kernels, += versus a separate add)
+        tol = 2e-3 * float(g1.abs().max()) + 1e-6
         assert float((g1 - p2.grad).abs().max()) <= tol, k
     names = {p.data_ptr(): k for k, p in m2.named_parameters()}
     seen = [names.get(a, "?") for _, a in fired]
@@ -246,3 +246,22 @@ def test_grad_sink_matches_autograd_accumulation(cuda):
     assert not missing and "?" not in seen, (missing, fired[:4])
     by_sink = {names[a] for kind, a in fired if kind == "sink"}
     assert "sru_layers.rnn_lst.1.weight" in by_sink and "cnn.weight" in by_sink and "classifier.0.weight" in by_sink
+
+
+def test_training_forward_is_bit_reproducible(cuda):
+    """Same parameters, same batch, training mode (batch statistics): the logits and the loss of two
+    runs are bit-identical -- the BatchNorm reductions use no float atomics."""
+    from speech_amd import ops
+    outs = []
+    for _ in range(2):
+        m = _small_model(cuda, torch.bfloat16)
+        m.train()
+        g = torch.Generator().manual_seed(3)
+        spec = (torch.rand(4, 1, 80, 301, generator=g) * 3).to(cuda)
+        labels = torch.randint(1, 29, (4, 20), generator=g).to(cuda)
+        lens = torch.tensor([20, 11, 15, 8], dtype=torch.int32, device=cuda)
+        out = m(spec)
+        il = torch.full((4,), out.shape[1], dtype=torch.int32, device=cuda)
+        loss = ops.ctc_loss(out.float(), labels, il, lens, blank=0, max_label_len=20)
+        outs.append((out.detach().clone(), loss.detach().clone()))
+    assert torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][1], outs[1][1])

@@ -148,15 +148,16 @@ int sp_adam_step_f32(float* p, const float* g, float* m, float* v, int64_t n, fl
  *   the pre-BN tensor); 2: out += epi_src (residual gradient).  Supported pairs: (0,0) (1,0) (2,1) (2,2).
  *   bn_sums (may be NULL): the BatchNorm reduction over the OUTPUT fused into the epilogue --
  *   epi_mode 0: what sp_bn_stats(out) gives; epi_mode 1: what sp_bn_bwd_reduce(out, epi_src) gives.
- *   Every `sums` / `bn_sums` buffer holds SP_BN_SUMS_WORDS floats: [0:64] the result, the rest one
- *   64-float partial per workgroup of the producing launch, summed in a fixed order (no float
- *   atomics): statistics, and with them every bf16 activation, are bit-reproducible.
+ *   Every `sums` / `bn_sums` buffer holds SP_BN_SUMS_WORDS floats: eight rows of 64 whose sum (taken
+ *   in a fixed order by the sp_bn_finalize_* consumers) is the result, followed by one 64-float
+ *   partial per workgroup of the producing launch.  No float atomics: statistics, and with them
+ *   every bf16 activation, are bit-reproducible.
  * sp_conv3x5_wgrad: gw[32][32][3][5] += sum_pos dy[pos][co] * a[pos + tap][ci], with
  *   a = a_src (a_mode 0) or relu(BN(a_src)) (a_mode 1), dy = g_coef affine of (g, y) as in_mode 2.
  *   gwp_ws: 8*15*32*32 f32 scratch (zeroed inside; one partial copy per XCD).
  * sp_conv_stem_fwd/bwd: Conv2d(1,32,3,stride 2,pad 1) on the f32 spectrogram [B][Fin][Tin] ->
  *   [B][F][T][32], F = (Fin-1)/2+1, T = (Tin-1)/2+1; bwd accumulates gw[32*9], gbias[32].
- * sp_bn_stats: sums[0:32] = sum y, sums[32:64] = sum y^2.
+ * sp_bn_stats: (sum y | sum y^2) per channel, as eight rows sums[8][64] to be added.
  * sp_bn_bwd_reduce: sums = (sum g, sum g*y).
  * sp_bn_finalize_fwd: coef = (scale, shift), save = (mean, invstd); training != 0 uses the batch
  *   sums and updates running stats (momentum, unbiased variance), else uses running stats.
@@ -165,7 +166,7 @@ int sp_adam_step_f32(float* p, const float* g, float* m, float* v, int64_t n, fl
  *   which lets the last block write the [T][B][F*32] layout the SRU stack reads.
  * sp_block_bwd_in: gpre = gz * [z > 0] (gz, z in that layout); sums = (sum gpre, sum gpre*y2).
  * --------------------------------------------------------------------------------------- */
-#define SP_BN_SUMS_WORDS (64 + 1024 * 64)
+#define SP_BN_SUMS_WORDS (8 * 64 + 1024 * 64)
 int sp_conv_pack_w(const float* w, int bwd_data, void* wpack, void* stream);
 int sp_conv3x5(const void* in, const void* in2, const float* coef, int in_mode, const void* wpack,
                const float* bias, const void* epi_src, const float* epi_coef, int epi_mode, int B,
@@ -196,11 +197,12 @@ int sp_block_bwd_in(const void* gz, const void* z, int64_t zsb, int64_t zsf, int
  * inverse for the gradient, summing S split-K partials [S][n_in][k][dir][d] of dtype into f32
  * dweight[n_in][dir][d][k] (overwritten, or added to when accumulate != 0: the caller's gradient
  * buffer).  sp_sru_pack_wt: the same weight transposed, WkT[k][dir][d][n_in] with row pitch ldo elements
- * (>= n_in): the K-contiguous B operand of sp_gemm_nt_bf16 for the forward projection; n_in % 32 == 0,
- * d % 64 == 0. */
+ * (>= n_in, even): the K-contiguous B operand of sp_gemm_nt_bf16 for the forward projection; with out_w
+ * != NULL the same pass also writes sp_sru_pack_w's Wk there (what the data gradient's GEMM reads).
+ * n_in % 64 == 0 (bf16; 32 for f32), d % 64 == 0. */
 int sp_sru_pack_w(const float* weight, int n_in, int d, int k, int C, int dtype, void* out, void* stream);
-int sp_sru_pack_wt(const float* weight, int n_in, int d, int k, int C, int dtype, void* out, int64_t ldo,
-                   void* stream);
+int sp_sru_pack_wt(const float* weight, int n_in, int d, int k, int C, int dtype, void* out_t, int64_t ldo,
+                   void* out_w, void* stream);
 int sp_sru_unpack_dw(const void* partials, int S, int n_in, int d, int k, int C, int dtype,
                      int accumulate, float* dweight, void* stream);
 

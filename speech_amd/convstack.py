@@ -29,7 +29,7 @@ def _pack(w, bwd_data):
 
 
 def _conv(inp, in2, coef, in_mode, wpack, bias, epi_src, epi_coef, epi_mode, B, F, T, bn_sums=None):
-    """bn_sums: optional f32 [BN_SUMS_WORDS] (result in [0:64]) receiving the BatchNorm reduction over the output (fused epilogue)."""
+    """bn_sums: optional f32 [BN_SUMS_WORDS] (result = the sum of its first eight rows of 64) receiving the BatchNorm reduction over the output (fused epilogue)."""
     out = torch.empty((B, F, T, C), dtype=torch.bfloat16, device=inp.device)
     check(lib().sp_conv3x5(ptr(inp), ptr(in2), ptr(coef), in_mode, ptr(wpack), ptr(bias), ptr(epi_src),
                            ptr(epi_coef), epi_mode, B, F, T, ptr(out), ptr(bn_sums), stream_ptr()), "sp_conv3x5")

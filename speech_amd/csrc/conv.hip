@@ -306,7 +306,7 @@ __global__ __launch_bounds__(256, 2) void conv3x5_kernel(
             const int c4 = tid >> 4, k = tid & 15;
             const float sm = red[(0 * 4 + c4) * 16 + k] + red[(1 * 4 + c4) * 16 + k] + red[(2 * 4 + c4) * 16 + k] +
                              red[(3 * 4 + c4) * 16 + k];
-            bn_sums[64 + blockIdx.x * 64 + (k >> 3) * 32 + c4 * 8 + (k & 7)] = sm;   // partial; see bn_sum_parts_kernel
+            bn_sums[(8 + blockIdx.x) * 64 + (k >> 3) * 32 + c4 * 8 + (k & 7)] = sm;   // partial; see bn_sum_parts_kernel
         }
     }
 }
@@ -586,7 +586,6 @@ __global__ __launch_bounds__(256) void bn_reduce_kernel(const __hip_bfloat16* __
                                                         const __hip_bfloat16* __restrict__ p1, int64_t n,
                                                         float* __restrict__ sums) {
     __shared__ float red[4][4][16];
-    const int ch4 = threadIdx.x & 3;
     float acc[16];
 #pragma unroll
     for (int i = 0; i < 16; ++i) acc[i] = 0.f;
@@ -627,26 +626,41 @@ __global__ __launch_bounds__(256) void bn_reduce_kernel(const __hip_bfloat16* __
     if (threadIdx.x < 64) {
         const int c4 = threadIdx.x >> 4, k = threadIdx.x & 15;
         const float s = red[0][c4][k] + red[1][c4][k] + red[2][c4][k] + red[3][c4][k];
-        sums[64 + blockIdx.x * 64 + (k >> 3) * 32 + c4 * 8 + (k & 7)] = s;
+        sums[(8 + blockIdx.x) * 64 + (k >> 3) * 32 + c4 * 8 + (k & 7)] = s;
     }
 }
 
-// sums[0..63] = sum over the producing launch's workgroups of their partials sums[64 + 64 b ..], in a
-// FIXED order (no float atomics): the BatchNorm statistics, and through them every bf16 activation of
-// the stack, are bit-reproducible from run to run and identical on data-parallel replicas.
+// Second level of the BatchNorm reductions.  The producing launch leaves one 64-float partial per
+// workgroup at sums[kBnL2 * 64 + 64 b ..]; workgroup g of this kernel adds the partials b = g, g + 8, ...
+// in a FIXED order into row g of sums[0 .. kBnL2 * 64), and the consumers (bn_finalize_*) add those
+// eight rows in a fixed order.  No float atomics anywhere: the statistics, and through them every bf16
+// activation of the stack, are bit-reproducible from run to run and identical on data-parallel
+// replicas.  (Eight workgroups, not one: a single CU fetches the up to 256 KB of partials at ~60 GB/s.)
+constexpr int kBnL2 = 8;
 __global__ __launch_bounds__(256) void bn_sum_parts_kernel(float* __restrict__ sums, int nparts) {
-    __shared__ float quarter[4][64];
+    __shared__ float grp[4][64];
     const int idx = threadIdx.x & 63, q = threadIdx.x >> 6;
-    float a0 = 0.f, a1 = 0.f;
-    int b = q;
-    for (; b + 4 < nparts; b += 8) {
-        a0 += sums[64 + b * 64 + idx];
-        a1 += sums[64 + (b + 4) * 64 + idx];
+    const float* part = sums + kBnL2 * 64;
+    float a[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) a[j] = 0.f;
+    // this workgroup's partials: b = blockIdx.x + 8 i; wave q takes i = q, q + 4, ...
+    for (int i0 = q; blockIdx.x + kBnL2 * i0 < nparts; i0 += 32) {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const int b = blockIdx.x + kBnL2 * (i0 + 4 * j);
+            if (b < nparts) a[j] += part[b * 64 + idx];
+        }
     }
-    if (b < nparts) a0 += sums[64 + b * 64 + idx];
-    quarter[q][idx] = a0 + a1;
+    grp[q][idx] = ((a[0] + a[1]) + (a[2] + a[3])) + ((a[4] + a[5]) + (a[6] + a[7]));
     __syncthreads();
-    if (threadIdx.x < 64) sums[idx] = (quarter[0][idx] + quarter[1][idx]) + (quarter[2][idx] + quarter[3][idx]);
+    if (threadIdx.x < 64) sums[blockIdx.x * 64 + idx] = (grp[0][idx] + grp[1][idx]) + (grp[2][idx] + grp[3][idx]);
+}
+
+// the consumers' read of a reduced sum: the eight second-level rows in a fixed order
+__device__ __forceinline__ float bn_sum8(const float* __restrict__ sums, int i) {
+    return ((sums[i] + sums[64 + i]) + (sums[128 + i] + sums[192 + i])) +
+           ((sums[256 + i] + sums[320 + i]) + (sums[384 + i] + sums[448 + i]));
 }
 
 // coef[0..31] = scale, coef[32..63] = shift; save[0..31] = mean, save[32..63] = invstd
@@ -658,8 +672,8 @@ __global__ void bn_finalize_fwd_kernel(const float* __restrict__ sums, float n, 
     if (c >= 32) return;
     float mean, var;
     if (training) {
-        mean = sums[c] / n;
-        var = fmaxf(sums[32 + c] / n - mean * mean, 0.f);
+        mean = bn_sum8(sums, c) / n;
+        var = fmaxf(bn_sum8(sums, 32 + c) / n - mean * mean, 0.f);
         rmean[c] = (1.f - momentum) * rmean[c] + momentum * mean;
         rvar[c] = (1.f - momentum) * rvar[c] + momentum * var * (n / fmaxf(n - 1.f, 1.f));
     } else {
@@ -682,7 +696,7 @@ __global__ void bn_finalize_bwd_kernel(const float* __restrict__ sums, const flo
     const int c = threadIdx.x;
     if (c >= 32) return;
     const float mean = save[c], invstd = save[32 + c];
-    const float sg = sums[c], sgy = sums[32 + c];
+    const float sg = bn_sum8(sums, c), sgy = bn_sum8(sums, 32 + c);
     const float dgamma = invstd * (sgy - mean * sg);
     const float a = gamma[c] * invstd;
     const float bq = -a * invstd * dgamma / n;
@@ -781,7 +795,7 @@ __global__ __launch_bounds__(256) void block_bwd_in_kernel(const __hip_bfloat16*
     if (threadIdx.x < 64) {
         const int c4 = threadIdx.x >> 4, k = threadIdx.x & 15;
         const float sm = red[0][c4][k] + red[1][c4][k] + red[2][c4][k] + red[3][c4][k];
-        sums[64 + blockIdx.x * 64 + (k >> 3) * 32 + c4 * 8 + (k & 7)] = sm;
+        sums[(8 + blockIdx.x) * 64 + (k >> 3) * 32 + c4 * 8 + (k & 7)] = sm;
     }
 }
 
@@ -840,7 +854,7 @@ extern "C" int sp_conv3x5(const void* in, const void* in2, const float* coef, in
     else if (in_mode == IN_BNBWD && epi_mode == EPI_ADD) SP_CONV_LAUNCH(IN_BNBWD, EPI_ADD);
     else return fail(SP_EINVAL, "sp_conv3x5: unsupported mode pair (%d, %d)", in_mode, epi_mode);
 #undef SP_CONV_LAUNCH
-    if (bn_sums) hipLaunchKernelGGL(bn_sum_parts_kernel, dim3(1), dim3(256), 0, s, bn_sums, (int)grid.x);
+    if (bn_sums) hipLaunchKernelGGL(bn_sum_parts_kernel, dim3(kBnL2), dim3(256), 0, s, bn_sums, (int)grid.x);
     return check_launch("conv3x5_kernel");
 }
 
@@ -896,7 +910,7 @@ extern "C" int sp_bn_stats(const void* y, int64_t npos, float* sums, void* strea
     const int nb = reduce_blocks(npos * 4);
     hipLaunchKernelGGL((bn_reduce_kernel<0>), dim3(nb), dim3(256), 0, s, (const bf16*)y,
                        (const bf16*)nullptr, npos, sums);
-    hipLaunchKernelGGL(bn_sum_parts_kernel, dim3(1), dim3(256), 0, s, sums, nb);
+    hipLaunchKernelGGL(bn_sum_parts_kernel, dim3(kBnL2), dim3(256), 0, s, sums, nb);
     return check_launch("bn_reduce_kernel<0>");
 }
 
@@ -906,7 +920,7 @@ extern "C" int sp_bn_bwd_reduce(const void* g, const void* y, int64_t npos, floa
     const int nb = reduce_blocks(npos * 4);
     hipLaunchKernelGGL((bn_reduce_kernel<1>), dim3(nb), dim3(256), 0, s, (const bf16*)g,
                        (const bf16*)y, npos, sums);
-    hipLaunchKernelGGL(bn_sum_parts_kernel, dim3(1), dim3(256), 0, s, sums, nb);
+    hipLaunchKernelGGL(bn_sum_parts_kernel, dim3(kBnL2), dim3(256), 0, s, sums, nb);
     return check_launch("bn_reduce_kernel<1>");
 }
 
@@ -957,6 +971,6 @@ extern "C" int sp_block_bwd_in(const void* gz, const void* z, int64_t zsb, int64
     else
         hipLaunchKernelGGL((block_bwd_in_kernel<false>), dim3(nb), dim3(256), 0, s, (const bf16*)gz, (const bf16*)z, zs,
                            (const bf16*)y2, B, F, T, (bf16*)gpre, sums);
-    hipLaunchKernelGGL(bn_sum_parts_kernel, dim3(1), dim3(256), 0, s, sums, nb);
+    hipLaunchKernelGGL(bn_sum_parts_kernel, dim3(kBnL2), dim3(256), 0, s, sums, nb);
     return check_launch("block_bwd_in_kernel");
 }

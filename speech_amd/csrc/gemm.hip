@@ -159,7 +159,7 @@ template <int MB>
 __global__ __launch_bounds__(512, 1) void gemm_nt_persist_kernel(
     const __hip_bfloat16* __restrict__ A, const __hip_bfloat16* __restrict__ B,
     __hip_bfloat16* __restrict__ C, int M, int N, int K, int lda, int ldb, int64_t ldc, int ntn, int ntiles) {
-    constexpr int BM = 64 * MB, WM = 32 * MB, ROWB = 128, BLK = 32 * ROWB;
+    constexpr int BM = 64 * MB, WM = 32 * MB, ROWB = 128;
     constexpr int STAGE = (BM + 256) * ROWB, EPI = 4096;
     __shared__ __attribute__((aligned(16))) unsigned char smem[2 * STAGE + 8 * EPI];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;

@@ -887,26 +887,58 @@ __global__ __launch_bounds__(256) void sru_pack_w_kernel(const float* __restrict
         Elem<T>::st(out + (((int64_t)r_out * K + kk) * 2 + dir) * d + dd, src[kk]);
 }
 
-// Transposed pack: out[n][r_out] (n = (kk*2 + dir)*d + dd, row length n_in), the K-contiguous "B" operand of
-// sp_gemm_nt_bf16.  One workgroup moves 32 rows x 64 dd x K through LDS: reads are 64*K consecutive floats
-// of one weight row, writes are 32 consecutive r_out of one output row.  Needs n_in % 32 == 0, d % 64 == 0.
+// Transposed pack: out_t[n][r_out] (n = (kk*2 + dir)*d + dd, row pitch ldo), the K-contiguous "B" operand
+// of sp_gemm_nt_bf16 -- and, in the same pass over the weight, optionally sru_pack_w's layout out_w as well
+// (the data gradient's library GEMM wants that one).  One workgroup moves R rows x 64 dd x K through LDS
+// (R x sizeof(T) = 128 bytes): reads are 64*K consecutive floats of one weight row, writes are 128-byte
+// runs of one output row.  Needs n_in % R == 0, d % 64 == 0.
 template <typename T, int K>
 __global__ __launch_bounds__(256) void sru_pack_wt_kernel(const float* __restrict__ w, int n_in, int d, int C,
-                                                          T* __restrict__ out, int64_t ldo) {
-    constexpr int W = 64 * K;
-    __shared__ float tile[32][W + 1];
-    const int r0 = blockIdx.x * 32, dd0 = blockIdx.y * 64, dir = blockIdx.z;
+                                                          T* __restrict__ out_t, int64_t ldo, T* __restrict__ out_w) {
+    constexpr int R = 128 / (int)sizeof(T), W = 64 * K, E = 4 / (int)sizeof(T);   // E elements per 4-byte store
+    __shared__ T tile[R][W + 2];
+    const int r0 = blockIdx.x * R, dd0 = blockIdx.y * 64, dir = blockIdx.z;
     const int F = n_in / C;
-    for (int idx = threadIdx.x; idx < 32 * W; idx += 256) {
-        const int row = idx / W, col = idx - row * W;
+    // all of a thread's 16-byte loads are requested before the first is used
+    constexpr int W4 = W / 4, NV = R * W4 / 256;
+    static_assert(R * W4 % 256 == 0, "tile must divide over the workgroup");
+    float4 v4[NV];
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+        const int idx = threadIdx.x + 256 * i, row = idx / W4, c4 = idx - row * W4;
         const int r_out = r0 + row, f = r_out / C, c = r_out - f * C;
-        tile[row][col] = w[(((int64_t)(c * F + f) * 2 + dir) * d + dd0) * K + col];
+        v4[i] = *reinterpret_cast<const float4*>(w + (((int64_t)(c * F + f) * 2 + dir) * d + dd0) * K + c4 * 4);
+    }
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+        const int idx = threadIdx.x + 256 * i, row = idx / W4, c4 = idx - row * W4;
+        Elem<T>::st(&tile[row][c4 * 4 + 0], v4[i].x);
+        Elem<T>::st(&tile[row][c4 * 4 + 1], v4[i].y);
+        Elem<T>::st(&tile[row][c4 * 4 + 2], v4[i].z);
+        Elem<T>::st(&tile[row][c4 * 4 + 3], v4[i].w);
     }
     __syncthreads();
-    const int rr = threadIdx.x & 31;
-    for (int pair = threadIdx.x >> 5; pair < W; pair += 8) {
+    const int lane32 = threadIdx.x & 31, sub = threadIdx.x >> 5;      // 8 half-waves, one 128-byte run each
+    // out_t: for every (kk, dd) the R rows are consecutive
+    for (int pair = sub; pair < W; pair += 8) {
         const int kk = pair / 64, ddl = pair - kk * 64;
-        Elem<T>::st(out + ((int64_t)(kk * 2 + dir) * d + dd0 + ddl) * ldo + r0 + rr, tile[rr][ddl * K + kk]);
+        T v[E];
+#pragma unroll
+        for (int e = 0; e < E; ++e) v[e] = tile[lane32 * E + e][ddl * K + kk];
+        T* dst = out_t + ((int64_t)(kk * 2 + dir) * d + dd0 + ddl) * ldo + r0 + lane32 * E;
+        *reinterpret_cast<uint32_t*>(dst) = *reinterpret_cast<const uint32_t*>(v);
+    }
+    if (out_w) {   // out_w: for every (row, kk) the 64 dd are consecutive; a half-wave moves 32 E of them
+        constexpr int RUNS = 64 / (32 * E);                           // half-wave runs per (row, kk): 1 (bf16) or 2 (f32)
+        for (int item = sub; item < R * K * RUNS; item += 8) {
+            const int run = item % RUNS, rk = item / RUNS, kk = rk % K, row = rk / K;
+            const int ddl = run * 32 * E + lane32 * E;
+            T v[E];
+#pragma unroll
+            for (int e = 0; e < E; ++e) v[e] = tile[row][(ddl + e) * K + kk];
+            T* dst = out_w + (((int64_t)(r0 + row) * K + kk) * 2 + dir) * d + dd0 + ddl;
+            *reinterpret_cast<uint32_t*>(dst) = *reinterpret_cast<const uint32_t*>(v);
+        }
     }
 }
 
@@ -955,18 +987,20 @@ extern "C" int sp_sru_pack_w(const float* weight, int n_in, int d, int k, int C,
     return check_launch("sru_pack_w_kernel");
 }
 
-extern "C" int sp_sru_pack_wt(const float* weight, int n_in, int d, int k, int C, int dtype, void* out,
-                              int64_t ldo, void* stream) {
+extern "C" int sp_sru_pack_wt(const float* weight, int n_in, int d, int k, int C, int dtype, void* out_t,
+                              int64_t ldo, void* out_w, void* stream) {
     using namespace sp;
     int rc = pack_check("sp_sru_pack_wt", n_in, d, k, C);
     if (rc) return rc;
-    SP_CHECK_ARG(weight && out, "sp_sru_pack_wt: null pointer");
+    SP_CHECK_ARG(weight && out_t, "sp_sru_pack_wt: null pointer");
     SP_CHECK_ARG(dtype == SP_F32 || dtype == SP_BF16, "sp_sru_pack_wt: dtype %d", dtype);
-    SP_CHECK_ARG(ldo >= n_in, "sp_sru_pack_wt: ldo=%lld smaller than n_in=%d", (long long)ldo, n_in);
-    SP_CHECK_ARG(n_in % 32 == 0 && d % 64 == 0, "sp_sru_pack_wt: n_in %% 32 and d %% 64 must be 0 (n_in=%d d=%d)", n_in, d);
+    const int R = dtype == SP_F32 ? 32 : 64;
+    SP_CHECK_ARG(ldo >= n_in && ldo % 2 == 0, "sp_sru_pack_wt: ldo=%lld must be even and >= n_in=%d", (long long)ldo, n_in);
+    SP_CHECK_ARG(n_in % R == 0 && d % 64 == 0, "sp_sru_pack_wt: n_in %% %d and d %% 64 must be 0 (n_in=%d d=%d)", R, n_in, d);
+    SP_CHECK_ARG((((uintptr_t)out_t | (uintptr_t)out_w) & 3) == 0, "sp_sru_pack_wt: outputs must be 4-byte aligned");
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
-    const dim3 grid(n_in / 32, d / 64, 2);
-#define SP_PACKT(T, K) hipLaunchKernelGGL((sru_pack_wt_kernel<T, K>), grid, dim3(256), 0, s, weight, n_in, d, C, (T*)out, ldo)
+    const dim3 grid(n_in / R, d / 64, 2);
+#define SP_PACKT(T, K) hipLaunchKernelGGL((sru_pack_wt_kernel<T, K>), grid, dim3(256), 0, s, weight, n_in, d, C, (T*)out_t, ldo, (T*)out_w)
     if (dtype == SP_F32) { if (k == 3) SP_PACKT(float, 3); else SP_PACKT(float, 4); }
     else { if (k == 3) SP_PACKT(__hip_bfloat16, 3); else SP_PACKT(__hip_bfloat16, 4); }
 #undef SP_PACKT

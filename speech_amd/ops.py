@@ -396,15 +396,17 @@ def sru_pack_w(weight, d, k, C, dtype):
     return out
 
 
-def sru_pack_wt(weight, d, k, C, dtype, pad=0):
+def sru_pack_wt(weight, d, k, C, dtype, pad=0, both=False):
     """state_dict weight f32 [n_in, 2*d*k] -> WkT [k*2*d, n_in] in dtype (columns f*C + c): sru_pack_w's
-    result transposed, the K-contiguous B operand of gemm_nt; pad: extra elements per row of the buffer."""
+    result transposed, the K-contiguous B operand of gemm_nt; pad: extra elements per row of the buffer.
+    both=True: returns (WkT, Wk), the second being sru_pack_w's layout written in the same pass."""
     n_in = weight.shape[0]
     out = torch.empty((k * 2 * d, n_in + pad), dtype=dtype, device=weight.device)[:, :n_in]
+    out_w = torch.empty((n_in, k * 2 * d), dtype=dtype, device=weight.device) if both else None
     with torch.cuda.device(weight.device):
         check(lib().sp_sru_pack_wt(ptr(weight), n_in, d, k, C, _lib.dtype_code(out), ptr(out), out.stride(0),
-                                   stream_ptr()), "sp_sru_pack_wt")
-    return out
+                                   ptr(out_w), stream_ptr()), "sp_sru_pack_wt")
+    return (out, out_w) if both else out
 
 
 def sru_unpack_dw(partials, n_in, d, k, C, out=None):
@@ -449,6 +451,8 @@ def _own_fwd_gemm(M, n_in, N, d, dtype):
     """The forward projection runs on sp_gemm_nt_bf16's persistent kernel where that was measured faster
     than the library GEMM (profiles/r01_gemm.md): bf16, output-heavy (N >= 2 n_in), enough rows for at
     least one 192-row tile per CU and column."""
+    if _os.environ.get("SPEECH_AMD_LIB_GEMM"):      # measurement switch: everything on the library GEMM
+        return False
     return (dtype == torch.bfloat16 and N % 256 == 0 and n_in % 64 == 0 and d % 64 == 0 and N >= 2 * n_in
             and (M // 192) * (N // 256) >= 256 and M * max(n_in, N) < (1 << 30))
 
@@ -472,13 +476,12 @@ class _SRULayerFn(torch.autograd.Function):
         own = _own_fwd_gemm(T * B, n_in, 2 * d * k, d, x.dtype)
         # rows whose pitch is a multiple of 1 KB land on few L2 channels when 256 CUs walk them in step
         pad = 64 if own and (n_in * x.element_size()) % 1024 == 0 else 0
-        if _os.environ.get('SP_NOPAD'): pad = 0
-        if _os.environ.get('SP_NOOWN'): own = False; pad = 0
         xn, mean, rstd = layernorm_fwd(x2, g32, b32, eps, pad)
         w32 = weight.detach().float().contiguous()
-        if own:      # wk holds W^T [N][n_in]
-            wk = sru_pack_wt(w32, d, k, C, x.dtype, pad)
-            U = gemm_nt(xn, wk)
+        if own:      # W^T [N][n_in] for the forward (own kernel), W [n_in][N] for the data gradient
+            wkt, wk = sru_pack_wt(w32, d, k, C, x.dtype, pad, both=True)
+            U = gemm_nt(xn, wkt)
+            del wkt
         else:        # wk holds W [n_in][N]
             wk = sru_pack_w(w32, d, k, C, x.dtype)
             U = torch.mm(xn, wk)
@@ -487,7 +490,6 @@ class _SRULayerFn(torch.autograd.Function):
         h, c = sru_fwd(U, xr, wc32, bs32, mask, T, B, d, k)
         ctx.save_for_backward(x2, xn, mean, rstd, g32, wk, U, wc32, bs32, mask, c)
         ctx.dims = (T, B, d, k, n_in, C)
-        ctx.wk_transposed = own
         ctx.pdt = (ln_w.dtype, ln_b.dtype, weight.dtype, wc.dtype, bias.dtype)
         ctx.params = (ln_w, ln_b, weight, wc, bias)
         return h
@@ -506,7 +508,7 @@ class _SRULayerFn(torch.autograd.Function):
         M = T * B
         S = 4 if (M % 4 == 0 and M >= 4096) else 1
         gw = sru_unpack_dw(_splitk_dw(xn, gU2, S), n_in, d, k, C, weight.grad if direct else None)
-        gxn = torch.mm(gU2, wk if ctx.wk_transposed else wk.t())
+        gxn = torch.mm(gU2, wk.t())
         gres = gxres.view(T * B, n_in) if k == 3 else None
         ln_direct = direct and C == 1   # layer 0's vectors are stored in the reference's c*F + f order
         gx, dg, db = layernorm_bwd(gxn, x2, mean, rstd, g32, gres, ln_w.grad if ln_direct else None,

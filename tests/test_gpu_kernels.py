@@ -449,10 +449,11 @@ def test_conv_kernels_individually(cuda, shape):
     # --- BN backward reduce / block backward entry
     from speech_amd._lib import BN_SUMS_WORDS
     sums_buf = torch.empty(BN_SUMS_WORDS, device=cuda)
-    sums = sums_buf[:64]
+    sums = sums_buf          # result = sum of the first eight rows of 64
+    red = lambda t: t[:512].view(8, 64).sum(0)
     check(lib().sp_bn_bwd_reduce(ptr(gten), ptr(yten), B * Fq * T, ptr(sums), stream_ptr()), "reduce")
     ref_s = torch.cat([gten.float().sum((0, 1, 2)), (gten.float() * yten.float()).sum((0, 1, 2))])
-    assert float((sums - ref_s).abs().max()) <= 2e-3 * float(ref_s.abs().max()) + 1e-2
+    assert float((red(sums) - ref_s).abs().max()) <= 2e-3 * float(ref_s.abs().max()) + 1e-2
     zten = _bf(rnd(B, Fq, T, 32))
     gpre = torch.empty_like(gten)
     check(lib().sp_block_bwd_in(ptr(gten), ptr(zten), Fq * T * 32, T * 32, 32, ptr(yten), B, Fq, T, ptr(gpre),
@@ -460,7 +461,7 @@ def test_conv_kernels_individually(cuda, shape):
     ref_g = gten.float() * (zten.float() > 0)
     assert torch.equal(gpre.float(), ref_g)
     ref_s = torch.cat([ref_g.sum((0, 1, 2)), (ref_g * yten.float()).sum((0, 1, 2))])
-    assert float((sums - ref_s).abs().max()) <= 2e-3 * float(ref_s.abs().max()) + 1e-2
+    assert float((red(sums) - ref_s).abs().max()) <= 2e-3 * float(ref_s.abs().max()) + 1e-2
     # --- BN finalize backward: coefficients reproduce torch's batch_norm backward
     n = B * Fq * T
     yv = yten.float().reshape(-1, 32).clone().requires_grad_(True)
@@ -541,7 +542,7 @@ def test_layernorm_fwd_bwd(cuda, dtype, tol, shape):
 
 
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
-@pytest.mark.parametrize("n_in,d,k,C", [(128, 64, 3, 1), (160, 64, 4, 32), (1280, 512, 4, 32)])
+@pytest.mark.parametrize("n_in,d,k,C", [(128, 64, 3, 1), (320, 64, 4, 32), (1280, 512, 4, 32)])
 def test_sru_weight_pack_unpack(cuda, dtype, n_in, d, k, C):
     """sp_sru_pack_w / sp_sru_unpack_dw against the index permutation written with torch views."""
     from speech_amd import ops
@@ -553,6 +554,8 @@ def test_sru_weight_pack_unpack(cuda, dtype, n_in, d, k, C):
     assert torch.equal(out.cpu(), ref.to(dtype))
     outT = ops.sru_pack_wt(w.to(cuda), d, k, C, dtype)                    # the same matrix, transposed
     assert outT.shape == (k * 2 * d, n_in) and torch.equal(outT.cpu(), ref.to(dtype).t())
+    outT2, out2 = ops.sru_pack_wt(w.to(cuda), d, k, C, dtype, pad=64, both=True)   # both layouts, padded pitch
+    assert outT2.stride(0) == n_in + 64 and torch.equal(outT2.cpu(), ref.to(dtype).t()) and torch.equal(out2, out)
     S = 3
     parts = torch.randn(S, n_in, k * 2 * d, generator=g).to(dtype)
     tot = parts.float().sum(0)
@@ -575,12 +578,12 @@ def test_conv_fused_bn_sums_are_reproducible(cuda):
     s2 = torch.full((BN_SUMS_WORDS,), float("nan"), device=cuda)     # nothing relies on a zeroed buffer
     y1 = cs._conv(x, None, None, cs.IN_ID, cs._pack(w, 0), bias, None, None, cs.EPI_NONE, B, F, T, s1)
     y2 = cs._conv(x, None, None, cs.IN_ID, cs._pack(w, 0), bias, None, None, cs.EPI_NONE, B, F, T, s2)
-    assert torch.equal(y1, y2) and torch.equal(s1[:64], s2[:64])
+    assert torch.equal(y1, y2) and torch.equal(s1[:512], s2[:512])
     s3 = torch.empty(BN_SUMS_WORDS, device=cuda)
     check(lib().sp_bn_stats(ptr(y1), B * F * T, ptr(s3), stream_ptr()), "sp_bn_stats")
     ref = torch.cat([y1.float().reshape(-1, 32).sum(0), y1.float().reshape(-1, 32).pow(2).sum(0)])
-    assert torch.allclose(s1[:64], ref, rtol=1e-4, atol=1e-2)
-    assert torch.allclose(s3[:64], ref, rtol=1e-4, atol=1e-2)
+    assert torch.allclose(s1[:512].view(8, 64).sum(0), ref, rtol=1e-4, atol=1e-2)
+    assert torch.allclose(s3[:512].view(8, 64).sum(0), ref, rtol=1e-4, atol=1e-2)
 
 
 # =============================================================================== hand-written GEMM

@@ -168,7 +168,7 @@ class SRModel(nn.Module):
         x = x.transpose(0, 1).contiguous()  # [B, T', 2*rnn_dim]
         ln, lin = self.classifier[0], self.classifier[1]
         x = ops.layer_norm(x, ln.weight, ln.bias, ln.eps)
-        return x @ lin.weight.to(cd).t()
+        return ops.classifier(x, lin.weight)      # f32 logits
 
     def load_checkpoint(self, obj):
         """Accept both checkpoint shapes of the reference: the dict train.py:171-178 saves

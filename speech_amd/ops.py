@@ -444,6 +444,51 @@ def _splitk_dw(xn, gU2, S):
     return torch.bmm(a, b, out_dtype=torch.float32) if _bmm_f32_out else torch.bmm(a, b)
 
 
+_mm_f32_out = None
+
+
+class _ClassifierFn(torch.autograd.Function):
+    """logits = x W^T (net.py:73-76, Linear without bias) with the two things the library's default
+    path does badly at these shapes handled by hand: the logits leave the GEMM in f32 (the CTC kernels
+    read f32; no bf16 round trip and no conversion pass over [B*T', V]), and the weight gradient
+    g^T x -- a [V, n] output, 16 tiles for 256 CUs -- is split 8 ways over the rows as one batched GEMM
+    with f32 partials."""
+
+    @staticmethod
+    def forward(ctx, x2d, weight):
+        global _mm_f32_out
+        wb = weight.detach().to(x2d.dtype)
+        if x2d.dtype == torch.float32:
+            out = torch.mm(x2d, wb.t())
+        else:
+            if _mm_f32_out is None:
+                try:
+                    torch.mm(x2d[:8], wb[:8].t(), out_dtype=torch.float32)
+                    _mm_f32_out = True
+                except (TypeError, RuntimeError):
+                    _mm_f32_out = False
+            out = torch.mm(x2d, wb.t(), out_dtype=torch.float32) if _mm_f32_out else torch.mm(x2d, wb.t()).float()
+        ctx.save_for_backward(x2d, wb)
+        ctx.wdtype = weight.dtype
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        x2d, wb = ctx.saved_tensors
+        gb = g.to(x2d.dtype).contiguous()
+        gx = torch.mm(gb, wb)
+        M = x2d.shape[0]
+        S = 8 if (M % 8 == 0 and M >= 8192) else 1
+        gw = _splitk_dw(gb, x2d, S).sum(0) if S > 1 else torch.mm(gb.t(), x2d)
+        return gx, gw.to(ctx.wdtype)
+
+
+def classifier(x, weight):
+    """x [..., n] (compute dtype) , weight [V, n] -> f32 logits [..., V]."""
+    lead = x.shape[:-1]
+    return _ClassifierFn.apply(x.reshape(-1, x.shape[-1]), weight).view(*lead, weight.shape[0])
+
+
 import os as _os
 
 

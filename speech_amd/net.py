@@ -160,15 +160,24 @@ class SRModel(nn.Module):
                                         nn.Linear(2 * rnn_dim, n_vocab + 1, bias=False))
         self.compute_dtype = compute_dtype
 
-    def forward(self, x):  # [B, 1, F, T] f32 spectrogram
+    def encode(self, x):
+        """[B, 1, F, T] f32 spectrogram -> layer-normed encoder output, time-major [T', B, 2*rnn_dim]."""
         cd = self.compute_dtype
         # conv stack on the channel-last bf16 kernels -> [T', B, (F/2)*32], feature = f*32 + c
         x = convstack.conv_stack(x, self.cnn, list(self.resnet_layers), self.training)
         x, _ = self.sru_layers(x.to(cd))
-        x = x.transpose(0, 1).contiguous()  # [B, T', 2*rnn_dim]
-        ln, lin = self.classifier[0], self.classifier[1]
-        x = ops.layer_norm(x, ln.weight, ln.bias, ln.eps)
-        return ops.classifier(x, lin.weight)      # f32 logits
+        ln = self.classifier[0]
+        return ops.layer_norm(x, ln.weight, ln.bias, ln.eps)
+
+    def forward(self, x):  # [B, 1, F, T] f32 spectrogram -> f32 logits [B, T', V]
+        x = self.encode(x).transpose(0, 1).contiguous()
+        return ops.classifier(x, self.classifier[1].weight)
+
+    def ctc_loss(self, x, labels, label_lengths, max_label_len=None):
+        """The training step's loss, CTCLoss(blank=0)(log_softmax(self(x)), ...) of train.py:69-77, with the
+        classifier and the loss as one node (ops.classifier_ctc_loss)."""
+        return ops.classifier_ctc_loss(self.encode(x), self.classifier[1].weight, labels, label_lengths, 0,
+                                       max_label_len)
 
     def load_checkpoint(self, obj):
         """Accept both checkpoint shapes of the reference: the dict train.py:171-178 saves

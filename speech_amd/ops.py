@@ -447,6 +447,22 @@ def _splitk_dw(xn, gU2, S):
 _mm_f32_out = None
 
 
+def _classifier_logits(x2d, weight):
+    """(f32 logits [M, V], the weight in the activation dtype)."""
+    global _mm_f32_out
+    wb = weight.detach().to(x2d.dtype)
+    if x2d.dtype == torch.float32:
+        return torch.mm(x2d, wb.t()), wb
+    if _mm_f32_out is None:
+        try:
+            torch.mm(x2d[:8], wb[:8].t(), out_dtype=torch.float32)
+            _mm_f32_out = True
+        except (TypeError, RuntimeError):
+            _mm_f32_out = False
+    out = torch.mm(x2d, wb.t(), out_dtype=torch.float32) if _mm_f32_out else torch.mm(x2d, wb.t()).float()
+    return out, wb
+
+
 class _ClassifierFn(torch.autograd.Function):
     """logits = x W^T (net.py:73-76, Linear without bias) with the two things the library's default
     path does badly at these shapes handled by hand: the logits leave the GEMM in f32 (the CTC kernels
@@ -456,18 +472,7 @@ class _ClassifierFn(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, x2d, weight):
-        global _mm_f32_out
-        wb = weight.detach().to(x2d.dtype)
-        if x2d.dtype == torch.float32:
-            out = torch.mm(x2d, wb.t())
-        else:
-            if _mm_f32_out is None:
-                try:
-                    torch.mm(x2d[:8], wb[:8].t(), out_dtype=torch.float32)
-                    _mm_f32_out = True
-                except (TypeError, RuntimeError):
-                    _mm_f32_out = False
-            out = torch.mm(x2d, wb.t(), out_dtype=torch.float32) if _mm_f32_out else torch.mm(x2d, wb.t()).float()
+        out, wb = _classifier_logits(x2d, weight)
         ctx.save_for_backward(x2d, wb)
         ctx.wdtype = weight.dtype
         return out
@@ -481,6 +486,42 @@ class _ClassifierFn(torch.autograd.Function):
         S = 8 if (M % 8 == 0 and M >= 8192) else 1
         gw = _splitk_dw(gb, x2d, S).sum(0) if S > 1 else torch.mm(gb.t(), x2d)
         return gx, gw.to(ctx.wdtype)
+
+
+class _HeadCTCFn(torch.autograd.Function):
+    """Classifier GEMM + CTC as ONE differentiable node for the training step (train.py:69-77 on
+    net.py:73-76's output): the logits stay time-major as the SRU stack leaves them (the CTC kernels take
+    strides, so the [T',B] -> [B,T'] copy and its backward disappear), the CTC gradient is taken once and
+    kept in the activation dtype, and the incoming scalar gradient multiplies the SMALL operands (W and
+    dW) instead of a pass over [T'*B, V]."""
+
+    @staticmethod
+    def forward(ctx, x_tm, weight, labels, label_lengths, blank, max_label_len):
+        T, B, n = x_tm.shape
+        x2d = x_tm.reshape(T * B, n)
+        logits, wb = _classifier_logits(x2d, weight)
+        logits = logits.view(T, B, -1)
+        ctx.wdtype = weight.dtype
+        il = torch.full((B,), T, dtype=torch.int32, device=x_tm.device)        # train.py:72-74: all T' frames
+        loss, _, grad = ctc_fwd_bwd(logits, labels, il, label_lengths, blank, max_label_len, True, 1.0, True)
+        ctx.save_for_backward(x2d, wb, grad.view(T * B, -1).to(x2d.dtype))
+        ctx.shape = (T, B, n)
+        return loss[0]
+
+    @staticmethod
+    def backward(ctx, g):
+        x2d, wb, gb = ctx.saved_tensors
+        gx = torch.mm(gb, (wb.float() * g).to(wb.dtype))
+        M = x2d.shape[0]
+        S = 8 if (M % 8 == 0 and M >= 8192) else 1
+        gw = _splitk_dw(gb, x2d, S).sum(0) if S > 1 else torch.mm(gb.t(), x2d).float()
+        return gx.view(ctx.shape), (gw * g).to(ctx.wdtype), None, None, None, None
+
+
+def classifier_ctc_loss(x_tm, weight, labels, label_lengths, blank=0, max_label_len=None):
+    """x_tm [T', B, n] (time-major, already layer-normed), weight [V, n] -> scalar CTC loss (mean
+    reduction over the batch of nll / label length, every utterance scored over all T' frames)."""
+    return _HeadCTCFn.apply(x_tm, weight, labels, label_lengths, blank, max_label_len)
 
 
 def classifier(x, weight):

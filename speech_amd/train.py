@@ -191,12 +191,15 @@ def train_step(model, optimizer, spectrograms, labels, label_lengths, clip_grad_
     sink = ops.GradSink(dp) if isinstance(optimizer, FlatAdam) else None
     ops.set_grad_sink(sink)
     try:
-        output = model(spectrograms)                                   # [B, T', V]
-        B, Tp, _ = output.shape
-        # train.py:72-74: every utterance is scored over all T' (padded) encoder frames
-        input_lengths = torch.full((B,), Tp, dtype=torch.int32, device=output.device)
-        loss = ops.ctc_loss(output.float(), labels, input_lengths, label_lengths, blank=0,
-                            max_label_len=max_label_len)
+        if hasattr(model, "ctc_loss"):      # SRModel: classifier + CTC as one node, time-major logits
+            loss = model.ctc_loss(spectrograms, labels, label_lengths, max_label_len)
+        else:
+            output = model(spectrograms)                                   # [B, T', V]
+            B, Tp, _ = output.shape
+            # train.py:72-74: every utterance is scored over all T' (padded) encoder frames
+            input_lengths = torch.full((B,), Tp, dtype=torch.int32, device=output.device)
+            loss = ops.ctc_loss(output.float(), labels, input_lengths, label_lengths, blank=0,
+                                max_label_len=max_label_len)
         loss.backward()
     finally:
         ops.set_grad_sink(None)

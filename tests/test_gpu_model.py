@@ -265,3 +265,34 @@ def test_training_forward_is_bit_reproducible(cuda):
         loss = ops.ctc_loss(out.float(), labels, il, lens, blank=0, max_label_len=20)
         outs.append((out.detach().clone(), loss.detach().clone()))
     assert torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][1], outs[1][1])
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_fused_head_matches_classifier_then_ctc(cuda, dtype):
+    """SRModel.ctc_loss (classifier + CTC as one node on time-major logits, what train_step uses) against
+    ops.ctc_loss(model(x)) (the reference's two steps, train.py:69-77): same loss, same gradients."""
+    from speech_amd import ops
+    g = torch.Generator().manual_seed(4)
+    spec = (torch.rand(3, 1, 80, 161, generator=g) * 3).to(cuda)
+    labels = torch.randint(1, 29, (3, 9), generator=g).to(cuda)
+    lens = torch.tensor([9, 5, 7], dtype=torch.int32, device=cuda)
+    res = []
+    for fused in (False, True):
+        m = _small_model(cuda, dtype)
+        m.train()
+        if fused:
+            loss = m.ctc_loss(spec, labels, lens, 9)
+        else:
+            out = m(spec)
+            il = torch.full((3,), out.shape[1], dtype=torch.int32, device=cuda)
+            loss = ops.ctc_loss(out.float(), labels, il, lens, blank=0, max_label_len=9)
+        (loss * 3.0).backward()          # a non-unit incoming gradient
+        res.append((loss.detach(), {k: p.grad.detach().clone() for k, p in m.named_parameters()}))
+    assert float((res[0][0] - res[1][0]).abs()) <= 1e-6 * float(res[0][0].abs())
+    for k in res[0][1]:
+        a, b = res[0][1][k], res[1][1][k]
+        # f32 stack: last-bit differences of the head; the conv stack keeps bf16 activation gradients, which
+        # turn those into rounding flips (5e-3).  bf16: the CTC gradient is rounded before the GEMMs (2e-2)
+        conv = k.startswith("cnn") or k.startswith("resnet")
+        tol = 2e-2 if dtype == torch.bfloat16 else (5e-3 if conv else 1e-5)
+        assert float((a - b).abs().max()) <= tol * float(a.abs().max()) + 1e-7, k

@@ -117,7 +117,7 @@ def kernel_rooflines(args, model, wav, offs, labels, lens, Lmax, V, iters):
     ws = torch.empty(L.sp_ctc_workspace_bytes(Tp, B, V, Lmax), dtype=torch.uint8, device=dev)
     ms = time_kernel(lambda: check(L.sp_ctc_fwd_bwd(ptr(logits), logits.stride(1), logits.stride(0), ptr(labels),
                                                     labels.stride(0), ptr(il), ptr(lens), Tp, B, V, 0, Lmax, 1.0,
-                                                    ptr(nll), ptr(loss), ptr(grad), ptr(ws), ws.numel(), st), "ctc"), iters)
+                                                    ptr(nll), ptr(loss), ptr(grad), 0, ptr(ws), ws.numel(), st), "ctc"), iters)
     S = (2 * lens.float() + 1).sum().item()
     line("ctc_fwd_bwd(3 kernels)", 2 * 4.0 * Tp * B * V + 2 * 8.0 * Tp * S, ms, 1)
     # decode: scores read + ids write

@@ -70,14 +70,16 @@ int sp_melspec_fwd(const float* wav, const int64_t* wav_offsets, int B, int T_ma
  * max_label_len: host upper bound on label_lengths (sizes the lattice; <= 1023).
  * Outputs: nll[B] (per-utterance negative log likelihood, +inf if infeasible), loss[1] =
  * mean_b nll_b / max(L_b,1), grad (may be NULL) laid out like logits =
- * grad_scale * d loss / d logits; frames t >= input_lengths[b] get 0.
+ * grad_scale * d loss / d logits, of grad_dtype SP_F32 or SP_BF16 (same strides in elements; bf16
+ * when the consumer is a bf16 GEMM: its rounding happens in the store); frames t >=
+ * input_lengths[b] get 0.
  * --------------------------------------------------------------------------------------- */
 size_t sp_ctc_workspace_bytes(int T, int B, int V, int max_label_len);
 int sp_ctc_fwd_bwd(const float* logits, int64_t stride_t, int64_t stride_b, const int64_t* labels,
                    int label_stride, const int32_t* input_lengths, const int32_t* label_lengths,
                    int T, int B, int V, int blank, int max_label_len, float grad_scale,
-                   float* nll, float* loss, float* grad, void* workspace, size_t workspace_bytes,
-                   void* stream);
+                   float* nll, float* loss, void* grad, int grad_dtype, void* workspace,
+                   size_t workspace_bytes, void* stream);
 
 /* ---------------------------------------------------------------------------------------
  * Greedy CTC decode.  Replaces decoder.py:28-57: argmax over V (ties -> lowest index, NaN

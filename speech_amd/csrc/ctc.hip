@@ -680,6 +680,21 @@ __global__ __launch_bounds__(192) void ctc_lattice1_kernel(
 // -------------------------------------------------------------------------------------------
 // K3: gradient rows (+ the scalar loss in block 0)
 // -------------------------------------------------------------------------------------------
+__device__ __forceinline__ void store4(float* g, int c, float a, float b, float x, float y) {
+    reinterpret_cast<float4*>(g)[c] = make_float4(a, b, x, y);
+}
+__device__ __forceinline__ void store4(__hip_bfloat16* g, int c, float a, float b, float x, float y) {
+    uint2 o;
+    o.x = (uint32_t)__builtin_bit_cast(unsigned short, __float2bfloat16(a)) |
+          ((uint32_t)__builtin_bit_cast(unsigned short, __float2bfloat16(b)) << 16);
+    o.y = (uint32_t)__builtin_bit_cast(unsigned short, __float2bfloat16(x)) |
+          ((uint32_t)__builtin_bit_cast(unsigned short, __float2bfloat16(y)) << 16);
+    reinterpret_cast<uint2*>(g)[c] = o;
+}
+
+// G = element type of the gradient (float, or bf16 when the consumer is a bf16 GEMM: the rounding the
+// caller would apply in a pass of its own happens in the store)
+template <typename G>
 __global__ __launch_bounds__(256) void ctc_grad_kernel(
     const float* __restrict__ logits, int64_t st, int64_t sb, const int64_t* __restrict__ labels,
     int label_stride, const int32_t* __restrict__ in_len, const int32_t* __restrict__ lab_len,
@@ -687,7 +702,7 @@ __global__ __launch_bounds__(256) void ctc_grad_kernel(
     const float* __restrict__ lse2, const float* __restrict__ rows, const double* __restrict__ alpha,
     const double* __restrict__ beta_rev, const double* __restrict__ aux,
     const double* __restrict__ nll2d, const float* __restrict__ nll, float grad_scale,
-    float* __restrict__ grad, float* __restrict__ loss) {
+    G* __restrict__ grad, float* __restrict__ loss) {
     extern __shared__ __attribute__((aligned(16))) float s_occ[];  // [waves][V]
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int wpb = blockDim.x >> 6;
@@ -707,13 +722,12 @@ __global__ __launch_bounds__(256) void ctc_grad_kernel(
     for (int64_t r = (int64_t)blockIdx.x * wpb + wave; r < nrows; r += (int64_t)gridDim.x * wpb) {
         const int b = (int)(r / T), t = (int)(r % T);
         const int Tb = min(max(in_len[b], 0), T);
-        float* g = grad + t * st + b * sb;
+        G* g = grad + t * st + b * sb;
         if (t >= Tb) {
             if (vec) {
-                for (int c = lane; c < (V >> 2); c += 64)
-                    reinterpret_cast<float4*>(g)[c] = make_float4(0.f, 0.f, 0.f, 0.f);
+                for (int c = lane; c < (V >> 2); c += 64) store4(g, c, 0.f, 0.f, 0.f, 0.f);
             } else {
-                for (int c = lane; c < V; c += 64) g[c] = 0.f;
+                for (int c = lane; c < V; c += 64) Elem<G>::st(g + c, 0.f);
             }
             continue;
         }
@@ -766,18 +780,17 @@ __global__ __launch_bounds__(256) void ctc_grad_kernel(
         if (vec) {
             const float4* z4 = reinterpret_cast<const float4*>(z);
             const float4* o4 = reinterpret_cast<const float4*>(occ);
-            float4* g4 = reinterpret_cast<float4*>(g);
             for (int c = lane; c < (V >> 2); c += 64) {
                 const float4 zz = z4[c], oo = o4[c];
-                g4[c] = make_float4((exp2f(fmaf(zz.x, kLog2e, -l2)) - oo.x) * scale,
-                                    (exp2f(fmaf(zz.y, kLog2e, -l2)) - oo.y) * scale,
-                                    (exp2f(fmaf(zz.z, kLog2e, -l2)) - oo.z) * scale,
-                                    (exp2f(fmaf(zz.w, kLog2e, -l2)) - oo.w) * scale);
+                store4(g, c, (exp2f(fmaf(zz.x, kLog2e, -l2)) - oo.x) * scale,
+                       (exp2f(fmaf(zz.y, kLog2e, -l2)) - oo.y) * scale,
+                       (exp2f(fmaf(zz.z, kLog2e, -l2)) - oo.z) * scale,
+                       (exp2f(fmaf(zz.w, kLog2e, -l2)) - oo.w) * scale);
             }
         } else {
             for (int c = lane; c < V; c += 64) {
                 const float sm = exp2f(fmaf(z[c], kLog2e, -l2));
-                g[c] = (sm - occ[c]) * scale;
+                Elem<G>::st(g + c, (sm - occ[c]) * scale);
             }
         }
         __builtin_amdgcn_wave_barrier();
@@ -810,8 +823,9 @@ extern "C" int sp_ctc_fwd_bwd(const float* logits, int64_t stride_t, int64_t str
                               const int64_t* labels, int label_stride, const int32_t* input_lengths,
                               const int32_t* label_lengths, int T, int B, int V, int blank,
                               int max_label_len, float grad_scale, float* nll, float* loss,
-                              float* grad, void* workspace, size_t workspace_bytes, void* stream) {
+                              void* grad, int grad_dtype, void* workspace, size_t workspace_bytes, void* stream) {
     using namespace sp;
+    SP_CHECK_ARG(!grad || grad_dtype == SP_F32 || grad_dtype == SP_BF16, "sp_ctc_fwd_bwd: grad_dtype %d", grad_dtype);
     SP_CHECK_ARG(T >= 0 && B >= 0 && V >= 1, "sp_ctc_fwd_bwd: bad shape T=%d B=%d V=%d", T, B, V);
     SP_CHECK_ARG(V <= kMaxV, "sp_ctc_fwd_bwd: V=%d exceeds the supported maximum %d", V, kMaxV);
     SP_CHECK_ARG(blank >= 0 && blank < V, "sp_ctc_fwd_bwd: blank %d outside [0,%d)", blank, V);
@@ -869,13 +883,18 @@ extern "C" int sp_ctc_fwd_bwd(const float* logits, int64_t stride_t, int64_t str
     if (grad || loss) {
         const int gb = (grad && T > 0) ? row_blocks : 1;
         const size_t lds = (size_t)4 * V * sizeof(float);
-        hipLaunchKernelGGL(ctc_grad_kernel, dim3(gb), dim3(256), lds, s, logits, stride_t, stride_b,
-                           labels, label_stride, input_lengths, label_lengths, T, B, V, blank,
-                           max_label_len, d.RW, d.SP, d.modeB, ws + d.off_lse, ws + d.off_rows,
-                           dbl, dbl + (size_t)B * T * d.SP,
-                           S <= 256 ? reinterpret_cast<const double*>(ws + d.off_aux) : nullptr,
-                           dbl + (size_t)2 * B * T * d.SP, nll,
-                           grad_scale, T > 0 ? grad : nullptr, loss);
+#define SP_GRAD_ARGS logits, stride_t, stride_b, labels, label_stride, input_lengths, label_lengths, T, B, V, blank,   \
+                     max_label_len, d.RW, d.SP, d.modeB, ws + d.off_lse, ws + d.off_rows, dbl,                      \
+                     dbl + (size_t)B * T * d.SP,                                                                      \
+                     S <= 256 ? reinterpret_cast<const double*>(ws + d.off_aux) : nullptr,                            \
+                     dbl + (size_t)2 * B * T * d.SP, nll, grad_scale
+        if (grad && grad_dtype == SP_BF16)
+            hipLaunchKernelGGL((ctc_grad_kernel<__hip_bfloat16>), dim3(gb), dim3(256), lds, s, SP_GRAD_ARGS,
+                               T > 0 ? (__hip_bfloat16*)grad : nullptr, loss);
+        else
+            hipLaunchKernelGGL((ctc_grad_kernel<float>), dim3(gb), dim3(256), lds, s, SP_GRAD_ARGS,
+                               T > 0 ? (float*)grad : nullptr, loss);
+#undef SP_GRAD_ARGS
         rc = check_launch("ctc_grad_kernel");
         if (rc) return rc;
     }

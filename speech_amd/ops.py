@@ -127,11 +127,14 @@ def _workspace(key, nbytes, device):
 
 
 def ctc_fwd_bwd(logits, labels, input_lengths, label_lengths, blank=0, max_label_len=None,
-                time_major=False, grad_scale=1.0, want_grad=True):
+                time_major=False, grad_scale=1.0, want_grad=True, grad_dtype=torch.float32):
     """logits [B,T,V] (or [T,B,V] when time_major) f32 -> (loss[1], nll[B], grad like logits).
 
-    loss = mean_b nll_b / max(L_b, 1) of log_softmax(logits); grad = grad_scale * dloss/dlogits.
+    loss = mean_b nll_b / max(L_b, 1) of log_softmax(logits); grad = grad_scale * dloss/dlogits, stored as
+    grad_dtype (float32, or bfloat16 for a bf16 consumer: rounded once, in the kernel's store).
     """
+    if grad_dtype not in (torch.float32, torch.bfloat16):
+        raise ValueError("grad_dtype must be float32 or bfloat16")
     _need_cuda(logits, "logits")
     if logits.dtype != torch.float32:
         raise ValueError("logits must be float32 (the reference computes CTC in fp32)")
@@ -157,16 +160,14 @@ def ctc_fwd_bwd(logits, labels, input_lengths, label_lengths, blank=0, max_label
         max_label_len = min(int(labels.shape[1]), 1023)
     nll = torch.empty(B, dtype=torch.float32, device=dev)
     loss = torch.empty(1, dtype=torch.float32, device=dev)
-    grad = torch.empty_like(logits) if want_grad else None
-    if grad is not None and grad.stride() != logits.stride():
-        grad = torch.empty_strided(logits.shape, logits.stride(), dtype=logits.dtype, device=dev)
+    grad = torch.empty_strided(logits.shape, logits.stride(), dtype=grad_dtype, device=dev) if want_grad else None
     nbytes = lib().sp_ctc_workspace_bytes(T, B, V, max_label_len)
     ws = _workspace((dev.index, "ctc"), nbytes, dev)
     with torch.cuda.device(dev):
         check(lib().sp_ctc_fwd_bwd(ptr(logits), st, sb, ptr(labels), labels.stride(0), ptr(input_lengths),
                                    ptr(label_lengths), T, B, V, blank, max_label_len, float(grad_scale),
-                                   ptr(nll), ptr(loss), ptr(grad), ptr(ws), ws.numel(), stream_ptr()),
-              "sp_ctc_fwd_bwd")
+                                   ptr(nll), ptr(loss), ptr(grad), _lib.dtype_code(grad) if grad is not None else 0,
+                                   ptr(ws), ws.numel(), stream_ptr()), "sp_ctc_fwd_bwd")
     return loss, nll, grad
 
 
@@ -503,8 +504,9 @@ class _HeadCTCFn(torch.autograd.Function):
         logits = logits.view(T, B, -1)
         ctx.wdtype = weight.dtype
         il = torch.full((B,), T, dtype=torch.int32, device=x_tm.device)        # train.py:72-74: all T' frames
-        loss, _, grad = ctc_fwd_bwd(logits, labels, il, label_lengths, blank, max_label_len, True, 1.0, True)
-        ctx.save_for_backward(x2d, wb, grad.view(T * B, -1).to(x2d.dtype))
+        loss, _, grad = ctc_fwd_bwd(logits, labels, il, label_lengths, blank, max_label_len, True, 1.0, True,
+                                    x2d.dtype)            # the gradient leaves the kernel in the GEMMs' dtype
+        ctx.save_for_backward(x2d, wb, grad.view(T * B, -1))
         ctx.shape = (T, B, n)
         return loss[0]
 

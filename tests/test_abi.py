@@ -39,7 +39,7 @@ def test_version_and_error_string():
     assert rc == -1 and b"bad shape" in h.sp_last_error()
     rc = h.sp_sru_fwd(None, None, None, None, None, 4, 2, 100, 3, 0, None, None, None)
     assert rc == -1 and b"multiple of 64" in h.sp_last_error()
-    rc = h.sp_ctc_fwd_bwd(None, 0, 0, None, 0, None, None, 10, 2, 5000, 0, 4, 1.0, None, None, None, None, 0, None)
+    rc = h.sp_ctc_fwd_bwd(None, 0, 0, None, 0, None, None, 10, 2, 5000, 0, 4, 1.0, None, None, None, 0, None, 0, None)
     assert rc == -1 and b"exceeds" in h.sp_last_error()
     assert h.sp_ctc_workspace_bytes(100, 4, 29, 20) > 0
     assert h.sp_melspec_plan_bytes() > 4 * (400 + 400)

@@ -564,6 +564,27 @@ def test_sru_weight_pack_unpack(cuda, dtype, n_in, d, k, C):
     assert torch.allclose(got.cpu(), back.reshape(n_in, -1), rtol=1e-6, atol=1e-6)
 
 
+@pytest.mark.parametrize("time_major,V", [(False, 1000), (True, 29)])
+def test_ctc_grad_in_bf16_is_the_rounded_f32_grad(cuda, time_major, V):
+    """grad_dtype = bf16 (the fused training head's choice): bit-identical to rounding the f32 gradient,
+    on the vectorised (V % 4 == 0) and the scalar store path, ragged input lengths included."""
+    from speech_amd import ops
+    g = torch.Generator().manual_seed(V)
+    B, T, L = 5, 77, 9
+    logits = (torch.randn(B, T, V, generator=g) * 2).to(cuda)
+    if time_major:
+        logits = logits.transpose(0, 1).contiguous()
+    labels = torch.randint(1, V, (B, L), generator=g).to(cuda)
+    il = torch.tensor([77, 60, 77, 33, 70], dtype=torch.int32, device=cuda)
+    ll = torch.tensor([9, 4, 7, 1, 9], dtype=torch.int32, device=cuda)
+    l32, n32, g32 = ops.ctc_fwd_bwd(logits, labels, il, ll, max_label_len=L, time_major=time_major)
+    l16, n16, g16 = ops.ctc_fwd_bwd(logits, labels, il, ll, max_label_len=L, time_major=time_major,
+                                    grad_dtype=torch.bfloat16)
+    assert g16.dtype == torch.bfloat16 and g16.stride() == g32.stride()
+    assert torch.equal(l32, l16) and torch.equal(n32, n16)
+    assert torch.equal(g16, g32.to(torch.bfloat16))
+
+
 def test_conv_fused_bn_sums_are_reproducible(cuda):
     """The statistics fused into the convolution epilogue equal sp_bn_stats of its output, and two
     launches give the same BITS (per-workgroup partials summed in a fixed order, no float atomics)."""

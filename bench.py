@@ -134,15 +134,15 @@ def kernel_rooflines(args, model, wav, offs, labels, lens, Lmax, V, iters):
     xr = torch.randn(Tp, B, 2 * d, device=dev).to(adt)
     wc = torch.randn(4 * d, device=dev) * 0.5
     bias = torch.zeros(4 * d, device=dev)
-    h = torch.empty(Tp, B, 2 * d, device=dev, dtype=adt); c = torch.empty(Tp, B, 2 * d, device=dev)
+    h = torch.empty(Tp, B, 2 * d, device=dev, dtype=adt); c = torch.empty(Tp, B, 2 * d, device=dev, dtype=adt)
     ms = time_kernel(lambda: check(L.sp_sru_fwd(ptr(U), ptr(xr), ptr(wc), ptr(bias), None, Tp, B, d, 3, dc, ptr(h), ptr(c), st),
                                    "sru_fwd"), iters)
-    line("sru_fwd_kernel", Tp * B * 2 * d * (3 * e + e + e + 4.0), ms, 10)
+    line("sru_fwd_kernel", Tp * B * 2 * d * (3 * e + e + e + e), ms, 10)          # c is saved in the activation dtype
     gh = torch.randn_like(h); gU = torch.empty_like(U); gx = torch.empty_like(xr)
     gwc = torch.zeros(4 * d, device=dev); gb = torch.zeros(4 * d, device=dev)
     ms = time_kernel(lambda: check(L.sp_sru_bwd(ptr(U), ptr(xr), ptr(wc), ptr(bias), None, ptr(c), ptr(gh), Tp, B, d, 3, dc,
                                                 ptr(gU), ptr(gx), ptr(gwc), ptr(gb), st), "sru_bwd"), iters)
-    line("sru_bwd_kernel", Tp * B * 2 * d * (3 * e + e + e + 4.0 + 3 * e + e), ms, 10)
+    line("sru_bwd_kernel", Tp * B * 2 * d * (3 * e + e + e + e + 3 * e + e), ms, 10)
     return out
 
 

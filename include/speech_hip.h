@@ -107,16 +107,18 @@ int sp_edit_distance(const int32_t* a, int na, const int32_t* b, int nb);
  *   xres [T*B][2][d]     highway input when k == 3 (the layer's un-normalised input)
  *   wc, bias [2][2][d]   (v_f | v_r), (b_f | b_r), f32
  *   mask [B][2][d] f32 or NULL   variational dropout mask on the cell state (already / (1-p))
- *   h   [T*B][2][d]      output, act dtype;   c [T*B][2][d] f32 cell states (kept for backward)
+ *   h   [T*B][2][d]      output, act dtype;   c [T*B][2][d] cell states kept for the backward, act
+ *                        dtype too (the recurrence runs in f32 registers; the sru package saves c in
+ *                        the activation dtype as well)
  * dtype = element type of U, xres, h, and of gh/gU/gxres in the backward.
  * Backward: gh is d loss / d h.  Writes gU (same layout as U), gxres ([T*B][2][d], k == 3
  * only, else may be NULL), and ACCUMULATES into gwc/gbias ([2][2][d] f32, caller zeroes).
  * --------------------------------------------------------------------------------------- */
 int sp_sru_fwd(const void* U, const void* xres, const float* wc, const float* bias,
-               const float* mask, int T, int B, int d, int k, int dtype, void* h, float* c,
+               const float* mask, int T, int B, int d, int k, int dtype, void* h, void* c,
                void* stream);
 int sp_sru_bwd(const void* U, const void* xres, const float* wc, const float* bias,
-               const float* mask, const float* c, const void* gh, int T, int B, int d, int k,
+               const float* mask, const void* c, const void* gh, int T, int B, int d, int k,
                int dtype, void* gU, void* gxres, float* gwc, float* gbias, void* stream);
 
 /* ---------------------------------------------------------------------------------------

@@ -185,230 +185,26 @@ __global__ __launch_bounds__(64) void sru_bwd_kernel(
 
 
 // ---------------------------------------------------------------------------------------------
-// Loader-ring variants (bf16, d % 128 == 0): the production path.
+// Loader-ring kernels (bf16): the production path.
 //
 // The register-pipelined kernels above are capped by the 64 outstanding vector-memory operations a
 // wave may have: 64 x 128 B per wave x (columns / 64) waves = 4 MB in flight chip-wide whatever the
-// unroll, i.e. ~1.8 TB/s at the observed latency.  Here a workgroup is 2 consumer waves (128
-// columns, one per lane) plus ONE loader wave that only issues LDS-DMA (global_load_lds_dwordx4,
-// 1 KiB per instruction = all four streams of one time step for the 128 columns) into an LDS ring,
-// so the same 64-deep queue holds 64 KiB.  Hand-off per chunk of CH steps: the loader waits with a
-// COUNTED vmcnt for the oldest chunk, all three waves meet at a raw s_barrier, the consumers read
-// that chunk with ds_read while the loader refills the slot the consumers released one chunk ago.
-// Loads past the end of the sequence are clamped re-loads so the count per chunk stays constant.
+// unroll, i.e. ~1.8 TB/s at the observed latency.  Here ONE loader wave per workgroup only issues
+// LDS-DMA (global_load_lds_dwordx4, up to 1 KiB per instruction) into an LDS ring, so the same
+// 64-deep queue holds up to 64 KiB.  Hand-off per chunk of CH steps: the loader waits with a COUNTED
+// vmcnt for the oldest chunk, all waves meet at a raw s_barrier, the consumers read that chunk with
+// ds_read while the loader refills the slot the consumers released one chunk ago.  Loads past the
+// end of the sequence are clamped re-loads so the count per chunk stays constant.
+//
+// Cell states on this path are SAVED in bf16 (the recurrence itself runs in f32 registers): the sru
+// package keeps c in the activation dtype too (its kernels are templated on one scalar type), and it
+// takes 49 MB per layer off the forward's stores and the backward's loads at the reference's sizes.
 // ---------------------------------------------------------------------------------------------
 typedef __attribute__((address_space(1))) const void* gptr_t;
 typedef __attribute__((address_space(3))) void* lptr_t;
 
 __device__ __forceinline__ float lds_bf16(const unsigned char* p) {
     return __uint_as_float(((uint32_t)*reinterpret_cast<const uint16_t*>(p)) << 16);
-}
-
-template <int K>
-__global__ __launch_bounds__(192) void sru_fwd_ring_kernel(
-    const __hip_bfloat16* __restrict__ U, const __hip_bfloat16* __restrict__ xres,
-    const float* __restrict__ wc, const float* __restrict__ bias, const float* __restrict__ mask,
-    int Tn, int B, int d, __hip_bfloat16* __restrict__ h, float* __restrict__ cst) {
-    constexpr int CH = 8, R = 8, ROW = 1024;
-    __shared__ __attribute__((aligned(16))) unsigned char ring[R * CH * ROW];
-    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    const int D2 = 2 * d;
-    const int col0 = blockIdx.x * 128;
-    const int b = col0 / D2, cd0 = col0 - b * D2, dir = cd0 / d;
-    const int nch = (Tn + CH - 1) / CH;
-    const int64_t ustep = (int64_t)B * K * D2, hstep = (int64_t)B * D2;
-
-    if (wave == 2) {
-        // ---- loader: lane = (stream, 16-byte piece) ----
-        const int stream = lane >> 4, c16 = lane & 15;
-        const __hip_bfloat16* base;
-        int64_t step;
-        if (K == 4 || stream < 3) {
-            base = U + (int64_t)b * K * D2 + (int64_t)stream * D2 + cd0 + c16 * 8;
-            step = ustep;
-        } else {
-            base = xres + (int64_t)b * D2 + cd0 + c16 * 8;
-            step = hstep;
-        }
-        auto issue = [&](int c) {
-#pragma unroll
-            for (int s = 0; s < CH; ++s) {
-                const int i = min(c * CH + s, Tn - 1);
-                const int64_t t = dir ? Tn - 1 - i : i;
-                __builtin_amdgcn_global_load_lds((gptr_t)(base + t * step),
-                                                 (lptr_t)(ring + (((c % R) * CH) + s) * ROW), 16, 0, 0);
-            }
-        };
-        for (int c = 0; c < R - 1; ++c) issue(c);
-        for (int c = 0; c < nch; ++c) {
-            asm volatile("s_waitcnt vmcnt(%0)" ::"n"((R - 2) * CH) : "memory");
-            __builtin_amdgcn_s_barrier();
-            issue(c + R - 1);
-        }
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // drain before the LDS is released
-        return;
-    }
-    // ---- consumers: one column per lane ----
-    const int cl = wave * 64 + lane;  // column within the workgroup
-    const int cd = cd0 + cl;
-    const float vf = wc[cd], vr = wc[D2 + cd];
-    const float bf = bias[cd], br = bias[D2 + cd];
-    const float m = mask ? mask[(int64_t)b * D2 + cd] : 1.f;
-    __hip_bfloat16* hb = h + (int64_t)b * D2 + cd;
-    float* cb = cst + (int64_t)b * D2 + cd;
-    float c = 0.f;
-    const float nvf = -kL2e * vf, nvr = -kL2e * vr, nbf = -kL2e * bf, nbr = -kL2e * br;
-    auto chunk = [&](int ch, auto guard) {
-        constexpr bool GUARD = decltype(guard)::value;
-        const unsigned char* slot = ring + ((ch % R) * CH) * ROW + cl * 2;
-        float v0[CH], a1[CH], a2[CH], x[CH];
-#pragma unroll
-        for (int s = 0; s < CH; ++s) {  // every LDS read of the chunk up front, off the serial chain
-            const unsigned char* row = slot + s * ROW;
-            v0[s] = lds_bf16(row);
-            a1[s] = fmaf(-kL2e, lds_bf16(row + 256), nbf);
-            a2[s] = fmaf(-kL2e, lds_bf16(row + 512), nbr);
-            x[s] = lds_bf16(row + 768);
-        }
-#pragma unroll
-        for (int s = 0; s < CH; ++s) {
-            const int i = ch * CH + s;
-            if (!GUARD || i < Tn) {
-                const int64_t t = dir ? Tn - 1 - i : i;
-                const float f = sigmoid_neg2(fmaf(nvf, c, a1[s]));
-                const float r = sigmoid_neg2(fmaf(nvr, c, a2[s]));
-                c = fmaf(c - v0[s], f, v0[s]);
-                const float hv = fmaf(fmaf(c, m, -x[s]), r, x[s]);
-                hb[t * hstep] = __float2bfloat16(hv);
-                cb[t * hstep] = c;
-            }
-        }
-    };
-    for (int ch = 0; ch < nch; ++ch) {
-        __builtin_amdgcn_s_barrier();
-        asm volatile("" ::: "memory");
-        if ((ch + 1) * CH <= Tn) chunk(ch, std::false_type{});
-        else chunk(ch, std::true_type{});
-    }
-}
-
-template <int K>
-__global__ __launch_bounds__(192) void sru_bwd_ring_kernel(
-    const __hip_bfloat16* __restrict__ U, const __hip_bfloat16* __restrict__ xres,
-    const float* __restrict__ wc, const float* __restrict__ bias, const float* __restrict__ mask,
-    const float* __restrict__ cst, const __hip_bfloat16* __restrict__ gh, int Tn, int B, int d,
-    __hip_bfloat16* __restrict__ gU, __hip_bfloat16* __restrict__ gxres, float* __restrict__ gwc,
-    float* __restrict__ gbias) {
-    constexpr int CH = 4, R = 8, ROW = 2048;  // row: u0 u1 u2 x' (4 x 256 B) | gh (256 B) | c_prev f32 (512 B)
-    __shared__ __attribute__((aligned(16))) unsigned char ring[R * CH * ROW];
-    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    const int D2 = 2 * d;
-    const int col0 = blockIdx.x * 128;
-    const int b = col0 / D2, cd0 = col0 - b * D2, dir = cd0 / d;
-    const int nch = (Tn + CH - 1) / CH;
-    const int64_t ustep = (int64_t)B * K * D2, hstep = (int64_t)B * D2;
-
-    if (wave == 2) {
-        const int stream = lane >> 4, c16 = lane & 15;
-        const __hip_bfloat16* base;
-        int64_t step;
-        if (K == 4 || stream < 3) {
-            base = U + (int64_t)b * K * D2 + (int64_t)stream * D2 + cd0 + c16 * 8;
-            step = ustep;
-        } else {
-            base = xres + (int64_t)b * D2 + cd0 + c16 * 8;
-            step = hstep;
-        }
-        // second instruction: lanes 0-15 gh (bf16, 8 columns each), lanes 16-47 c_prev (f32, 4 columns each)
-        const char* base2 = lane < 16 ? reinterpret_cast<const char*>(gh + (int64_t)b * D2 + cd0 + lane * 8)
-                                      : reinterpret_cast<const char*>(cst + (int64_t)b * D2 + cd0 + (lane - 16) * 4);
-        const int64_t step2 = lane < 16 ? hstep * 2 : hstep * 4;  // bytes
-        auto issue = [&](int c) {
-#pragma unroll
-            for (int s = 0; s < CH; ++s) {
-                const int jr = min(c * CH + s, Tn - 1);    // walk the forward order backwards
-                const int i = Tn - 1 - jr;
-                const int64_t t = dir ? Tn - 1 - i : i;
-                unsigned char* row = ring + (((c % R) * CH) + s) * ROW;
-                __builtin_amdgcn_global_load_lds((gptr_t)(base + t * step), (lptr_t)row, 16, 0, 0);
-                // c_prev: cell state of forward step i-1 (consumer substitutes 0 at i == 0)
-                const int ip = max(i - 1, 0);
-                const int64_t tp = dir ? Tn - 1 - ip : ip;
-                const int64_t t2 = lane < 16 ? t : tp;
-                if (lane < 48)
-                    __builtin_amdgcn_global_load_lds((gptr_t)(base2 + t2 * step2), (lptr_t)(row + 1024), 16, 0, 0);
-            }
-        };
-        for (int c = 0; c < R - 1; ++c) issue(c);
-        for (int c = 0; c < nch; ++c) {
-            asm volatile("s_waitcnt vmcnt(%0)" ::"n"((R - 2) * CH * 2) : "memory");
-            __builtin_amdgcn_s_barrier();
-            issue(c + R - 1);
-        }
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        return;
-    }
-    const int cl = wave * 64 + lane;
-    const int cd = cd0 + cl;
-    const float vf = wc[cd], vr = wc[D2 + cd];
-    const float bf = bias[cd], br = bias[D2 + cd];
-    const float m = mask ? mask[(int64_t)b * D2 + cd] : 1.f;
-    __hip_bfloat16* gUb = gU + (int64_t)b * K * D2 + cd;
-    __hip_bfloat16* gXb = (K == 3) ? gxres + (int64_t)b * D2 + cd : nullptr;
-    float gc = 0.f, gvf = 0.f, gvr = 0.f, gbf = 0.f, gbr = 0.f;
-    const float nvf = -kL2e * vf, nvr = -kL2e * vr, nbf = -kL2e * bf, nbr = -kL2e * br;
-    auto chunk = [&](int ch, auto guard) {
-        constexpr bool GUARD = decltype(guard)::value;
-        const unsigned char* slot = ring + ((ch % R) * CH) * ROW;
-        float v0[CH], f_[CH], r_[CH], x[CH], g[CH], cp[CH];
-#pragma unroll
-        for (int s = 0; s < CH; ++s) {  // gates depend only on loaded data: all off the serial chain
-            const unsigned char* row = slot + s * ROW;
-            const int jr = ch * CH + s;
-            v0[s] = lds_bf16(row + cl * 2);
-            const float u1 = lds_bf16(row + 256 + cl * 2), u2 = lds_bf16(row + 512 + cl * 2);
-            x[s] = lds_bf16(row + 768 + cl * 2);
-            g[s] = lds_bf16(row + 1024 + cl * 2);
-            cp[s] = *reinterpret_cast<const float*>(row + 1280 + cl * 4);
-            if (jr >= Tn - 1) cp[s] = 0.f;  // forward step 0 has no predecessor
-            f_[s] = sigmoid_neg2(fmaf(nvf, cp[s], fmaf(-kL2e, u1, nbf)));
-            r_[s] = sigmoid_neg2(fmaf(nvr, cp[s], fmaf(-kL2e, u2, nbr)));
-        }
-#pragma unroll
-        for (int s = 0; s < CH; ++s) {
-            const int jr = ch * CH + s;
-            if (!GUARD || jr < Tn) {
-                const int i = Tn - 1 - jr;
-                const int64_t t = dir ? Tn - 1 - i : i;
-                const float f = f_[s], r = r_[s];
-                const float cc = fmaf(cp[s] - v0[s], f, v0[s]);
-                const float gr = g[s] * fmaf(cc, m, -x[s]);
-                const float gx = g[s] * (1.f - r);
-                const float gct = fmaf(g[s] * r, m, gc);
-                const float dr = gr * r * (1.f - r);
-                const float g0 = gct * (1.f - f);
-                const float df = gct * (cp[s] - v0[s]) * f * (1.f - f);
-                gc = fmaf(gct, f, fmaf(df, vf, dr * vr));
-                gvf = fmaf(df, cp[s], gvf); gvr = fmaf(dr, cp[s], gvr); gbf += df; gbr += dr;
-                __hip_bfloat16* gp = gUb + t * ustep;
-                gp[0] = __float2bfloat16(g0);
-                gp[D2] = __float2bfloat16(df);
-                gp[2 * D2] = __float2bfloat16(dr);
-                if (K == 3) gXb[t * hstep] = __float2bfloat16(gx);
-                else gp[3 * D2] = __float2bfloat16(gx);
-            }
-        }
-    };
-    for (int ch = 0; ch < nch; ++ch) {
-        __builtin_amdgcn_s_barrier();
-        asm volatile("" ::: "memory");
-        if ((ch + 1) * CH <= Tn) chunk(ch, std::false_type{});
-        else chunk(ch, std::true_type{});
-    }
-    atomicAdd(&gwc[cd], gvf);
-    atomicAdd(&gwc[D2 + cd], gvr);
-    atomicAdd(&gbias[cd], gbf);
-    atomicAdd(&gbias[D2 + cd], gbr);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -419,9 +215,9 @@ __global__ __launch_bounds__(192) void sru_bwd_ring_kernel(
 //           (fma, exp, add, rcp, sub, fma per step); c goes to an LDS ring.
 //   output  one chunk behind: r = sigmoid(u2 + v_r c' + b_r), h = (c m - x') r + x' -- independent
 //           across steps -- then stores the chunk transposed through LDS: 16 bytes per lane
-//           (1 store of h and 2 of c per 8 steps instead of 16 narrow ones).
-// The ring kernels above keep both parts in one wave, which is issue-bound at ~40 instructions per
-// step with only two of a CU's four SIMDs occupied; here the chain wave carries ~13.
+//           (1 store of h and 1 of c per 8 steps instead of 16 narrow ones).
+// Chain and output in ONE wave would be issue-bound at ~40 instructions per step with only two of a
+// CU's four SIMDs occupied; here the chain wave carries ~13.
 // One raw s_barrier per chunk of 8 steps hands chunk j to the chain wave, chunk j-1 to the output
 // wave and slot (j-2) % R back to the loader.
 // ---------------------------------------------------------------------------------------------
@@ -429,11 +225,12 @@ template <int K>
 __global__ __launch_bounds__(192) void sru_fwd_split_kernel(
     const __hip_bfloat16* __restrict__ U, const __hip_bfloat16* __restrict__ xres,
     const float* __restrict__ wc, const float* __restrict__ bias, const float* __restrict__ mask,
-    int Tn, int B, int d, __hip_bfloat16* __restrict__ h, float* __restrict__ cst) {
+    int Tn, int B, int d, __hip_bfloat16* __restrict__ h, __hip_bfloat16* __restrict__ cst) {
     constexpr int CH = 8, R = 8, ROW = 512, R2 = 4;   // (R-2) chunks = 24 DMA ops = 24 KB in flight per workgroup
     __shared__ __attribute__((aligned(16))) unsigned char ring[R * CH * ROW];   // 32 KB
     __shared__ __attribute__((aligned(16))) float cring[R2][CH][64];            // 8 KB
     __shared__ __attribute__((aligned(16))) unsigned short htile[CH][64];       // 1 KB
+    __shared__ __attribute__((aligned(16))) unsigned short ctile[CH][64];       // 1 KB
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int D2 = 2 * d;
     const int col0 = blockIdx.x * 64;
@@ -501,7 +298,7 @@ __global__ __launch_bounds__(192) void sru_fwd_split_kernel(
     const float nvr = -kL2e * wc[D2 + cd], nbr = -kL2e * bias[D2 + cd];
     const float m = mask ? mask[(int64_t)b * D2 + cd] : 1.f;
     __hip_bfloat16* hb = h + (int64_t)b * D2 + cd0;
-    float* cb = cst + (int64_t)b * D2 + cd0;
+    __hip_bfloat16* cb = cst + (int64_t)b * D2 + cd0;
     float cprev = 0.f;
     for (int j = 0; j <= nch; ++j) {
         __builtin_amdgcn_s_barrier();
@@ -521,26 +318,18 @@ __global__ __launch_bounds__(192) void sru_fwd_split_kernel(
                 const float r = sigmoid_neg2(fmaf(nvr, cprev, a2[s]));
                 const float hv = fmaf(fmaf(cc[s], m, -x[s]), r, x[s]);
                 htile[s][lane] = __builtin_bit_cast(unsigned short, __float2bfloat16(hv));
+                ctile[s][lane] = __builtin_bit_cast(unsigned short, __float2bfloat16(cc[s]));
                 cprev = cc[s];
             }
             __builtin_amdgcn_wave_barrier();
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-            {   // h: lane = (step, 8-column piece), 16 bytes
+            {   // h and c: lane = (step, 8-column piece), 16 bytes each
                 const int s = lane >> 3, p8 = lane & 7;
                 const int i = cj * CH + s;
                 if (i < Tn) {
                     const int64_t t = dir ? Tn - 1 - i : i;
                     *reinterpret_cast<uint4*>(hb + t * hstep + p8 * 8) = *reinterpret_cast<const uint4*>(&htile[s][p8 * 8]);
-                }
-            }
-#pragma unroll
-            for (int hf = 0; hf < 2; ++hf) {   // c: lane = (step, 4-column piece), 16 bytes
-                const int s = hf * 4 + (lane >> 4), p4 = lane & 15;
-                const int i = cj * CH + s;
-                if (i < Tn) {
-                    const int64_t t = dir ? Tn - 1 - i : i;
-                    *reinterpret_cast<float4*>(cb + t * hstep + p4 * 4) =
-                        *reinterpret_cast<const float4*>(&cring[cj % R2][s][p4 * 4]);
+                    *reinterpret_cast<uint4*>(cb + t * hstep + p8 * 8) = *reinterpret_cast<const uint4*>(&ctile[s][p8 * 8]);
                 }
             }
             __builtin_amdgcn_wave_barrier();
@@ -556,7 +345,7 @@ __global__ __launch_bounds__(192) void sru_fwd_split_kernel(
 // so the serial chain is an add and an fma per step.  One workgroup = 64 columns, four waves,
 // chunks of 4 steps, one raw s_barrier per chunk; in interval j
 //   loader  refills the ring slot of chunk j-2 with chunk j+R-2 (one LDS-DMA per step: u0 u1 u2 x'
-//           gh c', 896 B);
+//           gh c', 768 B);
 //   f-side  chunk j:   f, 1-f, kappa, kappa c', A, q = c m - x'  -> LDS;  stores g0/df of chunk j-3;
 //   r-side  chunk j-1: r, dr, gx, G, Bv (q from the f-side) -> LDS; stores dr/gx; sums for v_r, b_r;
 //   chain   chunk j-2: gct = gc + G, gc = gct A + Bv, g0 = gct (1-f), df = gct kappa -> LDS tiles;
@@ -567,7 +356,7 @@ template <int K>
 __global__ __launch_bounds__(256) void sru_bwd_split_kernel(
     const __hip_bfloat16* __restrict__ U, const __hip_bfloat16* __restrict__ xres,
     const float* __restrict__ wc, const float* __restrict__ bias, const float* __restrict__ mask,
-    const float* __restrict__ cst, const __hip_bfloat16* __restrict__ gh, int Tn, int B, int d,
+    const __hip_bfloat16* __restrict__ cst, const __hip_bfloat16* __restrict__ gh, int Tn, int B, int d,
     __hip_bfloat16* __restrict__ gU, __hip_bfloat16* __restrict__ gxres, float* __restrict__ gwc,
     float* __restrict__ gbias) {
     constexpr int CH = 4, R = 12, ROW = 1024;   // (R-2) chunks = 40 DMA ops = 35 KB in flight per workgroup
@@ -592,7 +381,7 @@ __global__ __launch_bounds__(256) void sru_bwd_split_kernel(
     auto t_of = [&](int jr) { const int i = Tn - 1 - jr; return (int64_t)(dir ? Tn - 1 - i : i); };
 
     if (wave == 0) {
-        // ---- loader: lanes 0-31 (stream, piece) of U / x', 32-39 gh, 40-55 c' (f32), 56-63 idle ----
+        // ---- loader: lanes 0-31 (stream, piece) of U / x', 32-39 gh, 40-47 c' (bf16), 48-63 idle ----
         const char* base;
         int64_t stepb;   // bytes per time step
         if (lane < 32) {
@@ -608,8 +397,8 @@ __global__ __launch_bounds__(256) void sru_bwd_split_kernel(
             base = reinterpret_cast<const char*>(gh + (int64_t)b * D2 + cd0 + (lane - 32) * 8);
             stepb = hstep * 2;
         } else {
-            base = reinterpret_cast<const char*>(cst + (int64_t)b * D2 + cd0 + (min(lane, 55) - 40) * 4);
-            stepb = hstep * 4;
+            base = reinterpret_cast<const char*>(cst + (int64_t)b * D2 + cd0 + (min(lane, 47) - 40) * 8);
+            stepb = hstep * 2;
         }
         const bool is_cp = lane >= 40;
         auto issue = [&](int c) {
@@ -619,7 +408,7 @@ __global__ __launch_bounds__(256) void sru_bwd_split_kernel(
                 const int i = Tn - 1 - jr;
                 const int il = is_cp ? max(i - 1, 0) : i;   // c' = cell state of forward step i-1
                 const int64_t t = dir ? Tn - 1 - il : il;
-                if (lane < 56)
+                if (lane < 48)
                     __builtin_amdgcn_global_load_lds((gptr_t)(base + t * stepb),
                                                      (lptr_t)(ring + (((c % R) * CH) + s) * ROW), 16, 0, 0);
             }
@@ -652,7 +441,7 @@ __global__ __launch_bounds__(256) void sru_bwd_split_kernel(
                     u0[s] = lds_bf16(row + lane * 2);
                     a1[s] = fmaf(-kL2e, lds_bf16(row + 128 + lane * 2), nbf);
                     x[s] = lds_bf16(row + 384 + lane * 2);
-                    cp[s] = *reinterpret_cast<const float*>(row + 640 + lane * 4);
+                    cp[s] = lds_bf16(row + 640 + lane * 2);
                     if (j * CH + s >= Tn - 1) cp[s] = 0.f;   // forward step 0 has no predecessor
                 }
 #pragma unroll
@@ -707,7 +496,7 @@ __global__ __launch_bounds__(256) void sru_bwd_split_kernel(
                     const unsigned char* row = slot + s * ROW;
                     a2[s] = fmaf(-kL2e, lds_bf16(row + 256 + lane * 2), nbr);
                     g[s] = lds_bf16(row + 512 + lane * 2);
-                    cp[s] = *reinterpret_cast<const float*>(row + 640 + lane * 4);
+                    cp[s] = lds_bf16(row + 640 + lane * 2);
                     if (c * CH + s >= Tn - 1) cp[s] = 0.f;
                     q[s] = sq[c & 1][s][lane];
                 }
@@ -816,30 +605,29 @@ static int sru_check(const char* who, int Tn, int B, int d, int k, int dtype) {
 
 extern "C" int sp_sru_fwd(const void* U, const void* xres, const float* wc, const float* bias,
                           const float* mask, int T, int B, int d, int k, int dtype, void* h,
-                          float* c, void* stream) {
+                          void* c, void* stream) {
     using namespace sp;
     int rc = sru_check("sp_sru_fwd", T, B, d, k, dtype);
     if (rc) return rc;
     if (T == 0 || B == 0) return SP_OK;
     SP_CHECK_ARG(U && wc && bias && h && c && (k == 4 || xres), "sp_sru_fwd: null pointer");
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
-    if (dtype == SP_F32) return sru_fwd_t<float>(U, xres, wc, bias, mask, T, B, d, k, h, c, s);
+    if (dtype == SP_F32) return sru_fwd_t<float>(U, xres, wc, bias, mask, T, B, d, k, h, (float*)c, s);
     {   // role-split path (any d % 64 == 0)
         typedef __hip_bfloat16 bf;
         const int blocks = B * 2 * d / 64;
         if (k == 3)
             hipLaunchKernelGGL((sru_fwd_split_kernel<3>), dim3(blocks), dim3(192), 0, s, (const bf*)U, (const bf*)xres,
-                               wc, bias, mask, T, B, d, (bf*)h, c);
+                               wc, bias, mask, T, B, d, (bf*)h, (bf*)c);
         else
             hipLaunchKernelGGL((sru_fwd_split_kernel<4>), dim3(blocks), dim3(192), 0, s, (const bf*)U, (const bf*)xres,
-                               wc, bias, mask, T, B, d, (bf*)h, c);
+                               wc, bias, mask, T, B, d, (bf*)h, (bf*)c);
         return check_launch("sru_fwd_split_kernel");
     }
-    return sru_fwd_t<__hip_bfloat16>(U, xres, wc, bias, mask, T, B, d, k, h, c, s);
 }
 
 extern "C" int sp_sru_bwd(const void* U, const void* xres, const float* wc, const float* bias,
-                          const float* mask, const float* c, const void* gh, int T, int B, int d,
+                          const float* mask, const void* c, const void* gh, int T, int B, int d,
                           int k, int dtype, void* gU, void* gxres, float* gwc, float* gbias,
                           void* stream) {
     using namespace sp;
@@ -850,19 +638,18 @@ extern "C" int sp_sru_bwd(const void* U, const void* xres, const float* wc, cons
                  "sp_sru_bwd: null pointer");
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
     if (dtype == SP_F32)
-        return sru_bwd_t<float>(U, xres, wc, bias, mask, c, gh, T, B, d, k, gU, gxres, gwc, gbias, s);
+        return sru_bwd_t<float>(U, xres, wc, bias, mask, (const float*)c, gh, T, B, d, k, gU, gxres, gwc, gbias, s);
     {   // role-split path (any d % 64 == 0)
         typedef __hip_bfloat16 bf;
         const int blocks = B * 2 * d / 64;
         if (k == 3)
             hipLaunchKernelGGL((sru_bwd_split_kernel<3>), dim3(blocks), dim3(256), 0, s, (const bf*)U, (const bf*)xres,
-                               wc, bias, mask, c, (const bf*)gh, T, B, d, (bf*)gU, (bf*)gxres, gwc, gbias);
+                               wc, bias, mask, (const bf*)c, (const bf*)gh, T, B, d, (bf*)gU, (bf*)gxres, gwc, gbias);
         else
             hipLaunchKernelGGL((sru_bwd_split_kernel<4>), dim3(blocks), dim3(256), 0, s, (const bf*)U, (const bf*)xres,
-                               wc, bias, mask, c, (const bf*)gh, T, B, d, (bf*)gU, (bf*)gxres, gwc, gbias);
+                               wc, bias, mask, (const bf*)c, (const bf*)gh, T, B, d, (bf*)gU, (bf*)gxres, gwc, gbias);
         return check_launch("sru_bwd_split_kernel");
     }
-    return sru_bwd_t<__hip_bfloat16>(U, xres, wc, bias, mask, c, gh, T, B, d, k, gU, gxres, gwc, gbias, s);
 }
 
 // ----------------------------------------------------------------------------------------------

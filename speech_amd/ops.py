@@ -230,7 +230,7 @@ def edit_distance(a, b):
 def sru_fwd(U, xres, wc, bias, mask, T, B, d, k):
     _need_cuda(U, "U")
     h = torch.empty((T, B, 2 * d), dtype=U.dtype, device=U.device)
-    c = torch.empty((T, B, 2 * d), dtype=torch.float32, device=U.device)
+    c = torch.empty((T, B, 2 * d), dtype=U.dtype, device=U.device)
     with torch.cuda.device(U.device):
         check(lib().sp_sru_fwd(ptr(U), ptr(xres), ptr(wc), ptr(bias), ptr(mask), T, B, d, k,
                                _lib.dtype_code(U), ptr(h), ptr(c), stream_ptr()), "sp_sru_fwd")

@@ -31,8 +31,11 @@ HBM_PEAK_GBS = 8000.0      # MI355X_MICROARCH.md: HBM3E 8 TB/s
 # corrected as MI355X_MICROARCH.md "HBM" prescribes (FETCH_SIZE x2 for 16-byte-per-lane reads on
 # gfx950, KiB units): profiles/r01_pmc_traffic.md holds the raw numbers.  None = not collected.
 PMC_TRAFFIC_BYTES = {
-    ("sru_bwd_kernel", "bf16", 32, 15.0): 2 * 168258.1 * 1024 + 192768.0 * 1024,
-    ("sru_fwd_kernel", "bf16", 32, 15.0): 2 * 96184.6 * 1024 + 144192.0 * 1024,
+    ("sru_bwd_kernel", "bf16", 32, 15.0): 2 * 144264.0 * 1024 + 192768.0 * 1024,
+    ("sru_fwd_kernel", "bf16", 32, 15.0): 2 * 96184.9 * 1024 + 96128.0 * 1024,
+    # L2-miss side of the forward GEMM (tools/pmc_gemm.py fwd): B panels stay L2-resident per XCD, A is
+    # streamed once per owning XCD; algorithmic 55.5 MB read + 147.7 MB written
+    ("gemm_nt_bf16(forward projection)", "bf16", 32, 15.0): 2 * 140472.0 * 1024 + 144192.0 * 1024,
 }
 MFMA_BF16_PEAK_TF = 2500.0  # dense bf16
 
@@ -69,19 +72,32 @@ def synth_batch(B, N, V, seconds, device, vocab):
             lens.to(torch.int32).to(device), Lmax)
 
 
-def time_kernel(fn, iters):
+def time_kernel(fn, iters, spacer=None):
     """Average device time of fn() in ms, HIP events on the current stream (the stream the C-ABI
-    launches use: speech_amd passes torch's current stream)."""
+    launches use: speech_amd passes torch's current stream).  With `spacer` every launch is timed by its
+    own event pair and an HBM-bound launch runs between two of them: back-to-back dense-MFMA launches
+    pull the clock down within milliseconds, which the training step (where every GEMM sits between
+    streaming kernels) never sees."""
     for _ in range(3):
         fn()
-    start, end = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     torch.cuda.synchronize()
-    start.record()
-    for _ in range(iters):
+    if spacer is None:
+        start = torch.cuda.Event(enable_timing=True)
+        end = torch.cuda.Event(enable_timing=True)
+        start.record()
+        for _ in range(iters):
+            fn()
+        end.record()
+        torch.cuda.synchronize()
+        return start.elapsed_time(end) / iters
+    pairs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(iters)]
+    for a, b in pairs:
+        spacer()
+        a.record()
         fn()
-    end.record()
+        b.record()
     torch.cuda.synchronize()
-    return start.elapsed_time(end) / iters
+    return sum(a.elapsed_time(b) for a, b in pairs) / iters
 
 
 def kernel_rooflines(args, model, wav, offs, labels, lens, Lmax, V, iters):
@@ -144,6 +160,42 @@ def kernel_rooflines(args, model, wav, offs, labels, lens, Lmax, V, iters):
                                                 ptr(gU), ptr(gx), ptr(gwc), ptr(gb), st), "sru_bwd"), iters)
     line("sru_bwd_kernel", Tp * B * 2 * d * (3 * e + e + e + e + 3 * e + e), ms, 10)
     return out
+
+
+def gemm_in_step(step_fn, n_steps=2):
+    """Live duration of the hand-written forward-projection GEMM INSIDE the training step: every
+    ops.gemm_nt call of `n_steps` extra (untimed) steps is bracketed by its own HIP event pair on the
+    launch stream.  A back-to-back microbenchmark of a dense-MFMA kernel is not representative here (the
+    clock sags within milliseconds of continuous MFMA load, and the caches hold other data than in the
+    step), and profiles/r01_*_kernel_stats.csv averages mostly in-step launches."""
+    from speech_amd import ops
+    rec, orig = [], ops.gemm_nt
+
+    def timed(a, b, out=None):
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        r = orig(a, b, out)
+        e1.record()
+        rec.append((tuple(a.shape), b.shape[0], e0, e1))
+        return r
+    ops.gemm_nt = timed
+    try:
+        for i in range(n_steps):
+            step_fn(10 ** 6 + i)
+        torch.cuda.synchronize()
+    finally:
+        ops.gemm_nt = orig
+    by_shape = {}
+    for (M, K), N, e0, e1 in rec:
+        by_shape.setdefault((M, N, K), []).append(e0.elapsed_time(e1))
+    if not by_shape:
+        return None
+    (M, N, K), ts = max(by_shape.items(), key=lambda kv: len(kv[1]))      # the nine 1024 -> 3072 layers
+    ms, fl = sum(ts) / len(ts), 2.0 * M * N * K
+    return {"bound": "mfma", "achieved": fl / ms / 1e9, "peak": MFMA_BF16_PEAK_TF, "unit": "TFLOP/s",
+            "frac": fl / ms / 1e9 / MFMA_BF16_PEAK_TF, "ms": ms, "algorithmic_flops": fl,
+            "algorithmic_bytes": 2 * (M * K + N * K + M * N), "launches_per_step": len(ts) // n_steps,
+            "shape_mnk": [M, N, K], "timed": "in-step, one HIP event pair per launch"}
 
 
 def cpu_baseline(args, V):
@@ -248,6 +300,9 @@ def main():
         }
         if world == 1:
             ks = kernel_rooflines(args, model, wav, offs, labels, lens, Lmax, V, args.kernel_iters)
+            g = gemm_in_step(step) if args.dtype == "bf16" else None
+            if g is not None:
+                ks["gemm_nt_bf16(forward projection)"] = g
             # dominant = the hand-written kernel with the largest share of the training step
             dom = max(ks, key=lambda k: ks[k]["ms"] * ks[k]["launches_per_step"])
             r = dict(ks[dom])

@@ -158,19 +158,28 @@ __global__ __launch_bounds__(128 * WN, WN == 2 ? 2 : 1) void gemm_nt_bf16_kernel
 template <int MB>
 __global__ __launch_bounds__(512, 1) void gemm_nt_persist_kernel(
     const __hip_bfloat16* __restrict__ A, const __hip_bfloat16* __restrict__ B,
-    __hip_bfloat16* __restrict__ C, int M, int N, int K, int lda, int ldb, int64_t ldc, int ntn, int ntiles) {
+    __hip_bfloat16* __restrict__ C, int M, int N, int K, int lda, int ldb, int64_t ldc, int ntn, int ntm, int gcols) {
     constexpr int BM = 64 * MB, WM = 32 * MB, ROWB = 128;
     constexpr int STAGE = (BM + 256) * ROWB, EPI = 4096;
     __shared__ __attribute__((aligned(16))) unsigned char smem[2 * STAGE + 8 * EPI];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave >> 2, wn = wave & 3;
     const int nk = K / 64;
-    // XCD x owns the contiguous run [run0, run1) of tiles (N fastest); its workgroups take them round-robin
-    const int per_xcd = (ntiles + 7) / 8, nslots = gridDim.x >> 3;
-    const int run0 = (blockIdx.x & 7) * per_xcd, run1 = min(run0 + per_xcd, ntiles);
-    const int first = run0 + (blockIdx.x >> 3);
+    // XCD-aware tile ownership.  The eight XCDs (workgroup b runs on XCD b % 8) form a gcols x (8 / gcols)
+    // grid over the tile matrix: an XCD owns ntn / gcols whole tile COLUMNS of a contiguous range of tile
+    // rows, so its share of B (at most ~2 MB, chosen on the host) stays resident in its 4 MB L2 and every
+    // A panel it streams is used by all of its columns back to back.  Its workgroups take the tiles of
+    // that sub-matrix round-robin, columns fastest.
+    const int xcd = blockIdx.x & 7, nslots = gridDim.x >> 3;
+    const int cols_per = ntn / gcols, grows = 8 / gcols;
+    const int col0 = (xcd % gcols) * cols_per;
+    const int row_lo = (int)((int64_t)(xcd / gcols) * ntm / grows), row_hi = (int)((int64_t)(xcd / gcols + 1) * ntm / grows);
+    const int run1 = (row_hi - row_lo) * cols_per;       // tiles this XCD owns, local index 0 .. run1-1
+    const int first = blockIdx.x >> 3;
     if (first >= run1) return;
     const int count = (run1 - first + nslots - 1) / nslots;
+    auto tile_m = [&](int i) { return row_lo + i / cols_per; };
+    auto tile_n = [&](int i) { return col0 + i % cols_per; };
     const int total = count * nk;
 
     // ---- load cursor
@@ -179,7 +188,7 @@ __global__ __launch_bounds__(512, 1) void gemm_nt_persist_kernel(
     int ltile = first, lk = 0;
     int a_off[MB], b_off;
     auto set_tile = [&](int tile) {
-        const int m0 = (tile / ntn) * BM, n0 = (tile % ntn) * 256;
+        const int m0 = tile_m(tile) * BM, n0 = tile_n(tile) * 256;
 #pragma unroll
         for (int i = 0; i < MB; ++i)
             a_off[i] = min(m0 + (wave + 8 * i) * 8 + drow, M - 1) * lda + lchunk * 8;   // rows past M are never stored
@@ -262,7 +271,7 @@ __global__ __launch_bounds__(512, 1) void gemm_nt_persist_kernel(
     };
     // D[row = n][col = m]: lane = m (r), register q -> n = 8 (q >> 2) + 4 h + (q & 3)
     auto epilogue = [&](int tile) {
-        const int m0 = (tile / ntn) * BM + wm * WM, n0 = (tile % ntn) * 256 + wn * 64;
+        const int m0 = tile_m(tile) * BM + wm * WM, n0 = tile_n(tile) * 256 + wn * 64;
         const int erow = lane >> 3, ephys = lane & 7;
         const uint32_t ep = lds0 + 2 * STAGE + wave * EPI;
         const uint32_t ep_w = ep + r * ROWB + h * 8, ep_r = ep + erow * ROWB + ephys * 16;
@@ -356,16 +365,20 @@ extern "C" int sp_gemm_nt_bf16(const void* A, const void* B, void* C, int M, int
             const int64_t rounds = ((t + 7) / 8 + 31) / 32;
             if (best_cost < 0 || rounds * mb < best_cost) best_cost = rounds * mb, best_mb = mb;
         }
-        const int ntn = N / 256;
-        const int64_t t = (int64_t)((M + 64 * best_mb - 1) / (64 * best_mb)) * ntn;
-        SP_CHECK_ARG(t < ((int64_t)1 << 30), "sp_gemm_nt_bf16: too many tiles");
+        const int ntn = N / 256, ntm = (M + 64 * best_mb - 1) / (64 * best_mb);
+        SP_CHECK_ARG((int64_t)ntm * ntn < ((int64_t)1 << 30), "sp_gemm_nt_bf16: too many tiles");
+        // columns per XCD: as few as divide evenly, so that an XCD's B panels (256 x K x 2 bytes each) fit in
+        // half of its 4 MB L2
+        int gcols = 1;
+        for (int g = 8; g >= 1; g >>= 1)
+            if (ntn % g == 0 && (int64_t)(ntn / g) * 256 * K * 2 <= (2 << 20)) gcols = g;
         hipStream_t ps = reinterpret_cast<hipStream_t>(stream);
         if (best_mb == 4)
             hipLaunchKernelGGL((gemm_nt_persist_kernel<4>), dim3(256), dim3(512), 0, ps, (const __hip_bfloat16*)A,
-                               (const __hip_bfloat16*)B, (__hip_bfloat16*)C, M, N, K, (int)lda, (int)ldb, ldc, ntn, (int)t);
+                               (const __hip_bfloat16*)B, (__hip_bfloat16*)C, M, N, K, (int)lda, (int)ldb, ldc, ntn, ntm, gcols);
         else
             hipLaunchKernelGGL((gemm_nt_persist_kernel<3>), dim3(256), dim3(512), 0, ps, (const __hip_bfloat16*)A,
-                               (const __hip_bfloat16*)B, (__hip_bfloat16*)C, M, N, K, (int)lda, (int)ldb, ldc, ntn, (int)t);
+                               (const __hip_bfloat16*)B, (__hip_bfloat16*)C, M, N, K, (int)lda, (int)ldb, ldc, ntn, ntm, gcols);
         return check_launch("gemm_nt_persist_kernel");
     }
     const bool wide = N % 256 == 0 && (int64_t)((M + kBM - 1) / kBM) * (N / 256) >= 256;   // enough 256 x 256 tiles to fill the chip

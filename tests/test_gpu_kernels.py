@@ -609,7 +609,8 @@ def test_conv_fused_bn_sums_are_reproducible(cuda):
 
 # =============================================================================== hand-written GEMM
 @pytest.mark.parametrize("M,N,K", [(256, 128, 32), (300, 256, 96), (1000, 384, 1024), (24032, 1024, 3072),
-                                   (24032, 3072, 1024), (12345, 2048, 192), (49155, 256, 64)])
+                                   (24032, 3072, 1024), (12345, 2048, 192), (49155, 256, 64),
+                                   (100, 65536, 64), (200001, 256, 128), (24032, 4096, 1280)])
 def test_gemm_nt_bf16(cuda, M, N, K):
     """sp_gemm_nt_bf16 against an f32 matmul of the same bf16 operands (ragged M, strided rows)."""
     from speech_amd import ops

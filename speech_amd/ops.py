@@ -1,6 +1,7 @@
 """Tensor-level wrappers over the C ABI (libspeech_hip.so).  torch supplies device memory and
 the current HIP stream; every computation below runs in the hand-written gfx950 kernels."""
 import ctypes
+import os as _os
 
 import numpy as np
 import torch
@@ -530,9 +531,6 @@ def classifier(x, weight):
     """x [..., n] (compute dtype) , weight [V, n] -> f32 logits [..., V]."""
     lead = x.shape[:-1]
     return _ClassifierFn.apply(x.reshape(-1, x.shape[-1]), weight).view(*lead, weight.shape[0])
-
-
-import os as _os
 
 
 def _own_fwd_gemm(M, n_in, N, d, dtype):

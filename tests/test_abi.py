@@ -41,6 +41,26 @@ def test_version_and_error_string():
     assert rc == -1 and b"multiple of 64" in h.sp_last_error()
     rc = h.sp_ctc_fwd_bwd(None, 0, 0, None, 0, None, None, 10, 2, 5000, 0, 4, 1.0, None, None, None, 0, None, 0, None)
     assert rc == -1 and b"exceeds" in h.sp_last_error()
+    rc = h.sp_ctc_fwd_bwd(None, 0, 0, None, 0, None, None, 10, 2, 29, 0, 4, 1.0, None, None, 1, 7, None, 0, None)
+    assert rc == -1 and b"grad_dtype" in h.sp_last_error()
+    # the hand-written GEMM: shape, pitch and alignment rules (no launch happens on a refusal)
+    rc = h.sp_gemm_nt_bf16(16, 16, 16, 256, 100, 64, 64, 64, 128, None)
+    assert rc == -1 and b"multiple of 128" in h.sp_last_error()
+    rc = h.sp_gemm_nt_bf16(16, 16, 16, 256, 128, 48, 64, 64, 128, None)
+    assert rc == -1 and b"multiple of 128" in h.sp_last_error()          # K % 32
+    rc = h.sp_gemm_nt_bf16(16, 16, 16, 256, 128, 64, 60, 64, 128, None)
+    assert rc == -1 and b"leading dimensions" in h.sp_last_error()
+    rc = h.sp_gemm_nt_bf16(None, 16, 16, 256, 128, 64, 64, 64, 128, None)
+    assert rc == -1 and b"null pointer" in h.sp_last_error()
+    rc = h.sp_gemm_nt_bf16(8, 16, 16, 256, 128, 64, 64, 64, 128, None)
+    assert rc == -1 and b"aligned" in h.sp_last_error()
+    assert h.sp_gemm_nt_bf16(None, None, None, 0, 128, 64, 64, 64, 128, None) == 0      # M = 0: nothing to do
+    rc = h.sp_sru_pack_wt(16, 96, 64, 3, 1, 2, 16, 96, None, None)
+    assert rc == -1 and b"n_in" in h.sp_last_error()                     # bf16 tiles are 64 rows
+    rc = h.sp_sru_pack_wt(16, 128, 64, 3, 1, 2, 16, 100, None, None)
+    assert rc == -1 and b"ldo" in h.sp_last_error()
+    rc = h.sp_layernorm_fwd(16, 16, 16, 4, 64, 1e-5, 0, 16, 60, 16, 16, None)
+    assert rc == -1 and b"ldy" in h.sp_last_error()
     assert h.sp_ctc_workspace_bytes(100, 4, 29, 20) > 0
     assert h.sp_melspec_plan_bytes() > 4 * (400 + 400)
 

@@ -144,7 +144,8 @@ int sp_adam_step_f32(float* p, const float* g, float* m, float* v, int64_t n, fl
  * Activations are channel-last bf16 [B][F][T][32]; N = B*F*T positions.
  *
  * sp_conv_pack_w: f32 weight [32][32][3][5] -> bf16 MFMA fragment image (15*2*64*8 elements);
- *   bwd_data != 0 packs the flipped, channel-transposed weight of the data gradient.
+ *   bwd_data 1 packs the flipped, channel-transposed weight of the data gradient, 2 both images
+ *   (forward at wpack[0], backward-data at wpack[15*2*64*8]) in one launch.
  * sp_conv3x5: out = conv(tf(in)) (+ bias).  in_mode 0: tf = id; 1: tf = relu(c[0:32]*in + c[32:64])
  *   (BatchNorm+ReLU of the producer, applied while staging); 2: tf = c[0:32]*in + c[32:64]*in2 +
  *   c[64:96] (BatchNorm backward from (dz, y)).  Zero padding applies after tf.  epi_mode 0: none

@@ -28,6 +28,24 @@ def _pack(w, bwd_data):
     return out
 
 
+def _pack_both(w):
+    """(forward image, backward-data image) of one convolution weight, one launch."""
+    out = torch.empty(2 * PACK_ELEMS, dtype=torch.bfloat16, device=w.device)
+    check(lib().sp_conv_pack_w(ptr(w), 2, ptr(out), stream_ptr()), "sp_conv_pack_w")
+    return out[:PACK_ELEMS], out[PACK_ELEMS:]
+
+
+_wgrad_ws = {}
+
+
+def _wgrad_workspace(dev):
+    """sp_conv3x5_wgrad's scratch: zeroed once here, handed back zeroed by every call."""
+    key = dev.index if dev.index is not None else torch.cuda.current_device()
+    if key not in _wgrad_ws:
+        _wgrad_ws[key] = torch.zeros(8 * 15 * 32 * 32, dtype=torch.float32, device=dev)
+    return _wgrad_ws[key]
+
+
 def _conv(inp, in2, coef, in_mode, wpack, bias, epi_src, epi_coef, epi_mode, B, F, T, bn_sums=None):
     """bn_sums: optional f32 [BN_SUMS_WORDS] (result = the sum of its first eight rows of 64) receiving the BatchNorm reduction over the output (fused epilogue)."""
     out = torch.empty((B, F, T, C), dtype=torch.bfloat16, device=inp.device)
@@ -71,9 +89,11 @@ class _ConvStackFn(torch.autograd.Function):
                 rm1, rv1, rm2, rv2 = bufs[4 * i: 4 * i + 4]
                 s1 = torch.empty(BN_SUMS_WORDS, dtype=torch.float32, device=dev) if training else None
                 s2 = torch.empty(BN_SUMS_WORDS, dtype=torch.float32, device=dev) if training else None
-                y1 = _conv(x, None, None, IN_ID, _pack(c1w, 0), c1b, None, None, EPI_NONE, B, F, T, s1)
+                p1f, p1b = _pack_both(c1w) if training else (_pack(c1w, 0), None)
+                p2f, p2b = _pack_both(c2w) if training else (_pack(c2w, 0), None)
+                y1 = _conv(x, None, None, IN_ID, p1f, c1b, None, None, EPI_NONE, B, F, T, s1)
                 coef1, save1 = _bn_fwd(s1, npos, b1w, b1b, rm1, rv1, momentum, eps, training)
-                y2 = _conv(y1, None, coef1, IN_BNRELU, _pack(c2w, 0), c2b, None, None, EPI_NONE, B, F, T, s2)
+                y2 = _conv(y1, None, coef1, IN_BNRELU, p2f, c2b, None, None, EPI_NONE, B, F, T, s2)
                 coef2, save2 = _bn_fwd(s2, npos, b2w, b2b, rm2, rv2, momentum, eps, training)
                 last = i == nblk - 1
                 if last:   # [T][B][F*32]
@@ -84,7 +104,7 @@ class _ConvStackFn(torch.autograd.Function):
                     zs = (F * T * C, T * C, C)
                 check(lib().sp_block_out(ptr(y2), ptr(coef2), ptr(x), B, F, T, ptr(z), zs[0], zs[1], zs[2], s),
                       "sp_block_out")
-                saved.append((x, y1, y2, z, zs, coef1, save1, save2, c1w, c2w, b1w, b2w))
+                saved.append((x, y1, y2, z, zs, coef1, save1, save2, c1w, c2w, b1w, b2w, p1b, p2b))
                 x = z
         ctx.saved = saved
         ctx.params = (stem_w, stem_b) + tuple(params)
@@ -110,9 +130,9 @@ class _ConvStackFn(torch.autograd.Function):
         direct = sink is not None and sink.ok(*P)   # accumulate straight into the parameters' .grad
         with torch.cuda.device(dev):
             s = stream_ptr()
-            ws = torch.empty(8 * 15 * 32 * 32, dtype=torch.float32, device=dev)
+            ws = _wgrad_workspace(dev)
             for i in range(nblk - 1, -1, -1):
-                x, y1, y2, z, zs, coef1, save1, save2, c1w, c2w, b1w, b2w = ctx.saved[i]
+                x, y1, y2, z, zs, coef1, save1, save2, c1w, c2w, b1w, b2w, p1b, p2b = ctx.saved[i]
                 if direct:
                     pc1w, pc1b, pb1w, pb1b, pc2w, pc2b, pb2w, pb2b = P[2 + 8 * i: 10 + 8 * i]
                     gw1, gg1, gb1, gw2, gg2, gb2 = pc1w.grad, pb1w.grad, pb1b.grad, pc2w.grad, pb2w.grad, pb2b.grad
@@ -129,12 +149,12 @@ class _ConvStackFn(torch.autograd.Function):
                 check(lib().sp_bn_finalize_bwd(ptr(sums), ptr(save2), ptr(b2w), npos, ptr(c3_2), ptr(gg2),
                                                ptr(gb2), s), "sp_bn_finalize_bwd")
                 # (sum g1pre, sum g1pre * y1) for BatchNorm-1's backward comes out of this epilogue
-                g1pre = _conv(g2pre, y2, c3_2, IN_BNBWD, _pack(c2w, 1), None, y1, coef1, EPI_MASK, B, F, T, sums)
+                g1pre = _conv(g2pre, y2, c3_2, IN_BNBWD, p2b, None, y1, coef1, EPI_MASK, B, F, T, sums)
                 check(lib().sp_conv3x5_wgrad(ptr(y1), ptr(coef1), IN_BNRELU, ptr(g2pre), ptr(y2), ptr(c3_2),
                                              B, F, T, ptr(ws), ptr(gw2), s), "sp_conv3x5_wgrad")
                 check(lib().sp_bn_finalize_bwd(ptr(sums), ptr(save1), ptr(b1w), npos, ptr(c3_1), ptr(gg1),
                                                ptr(gb1), s), "sp_bn_finalize_bwd")
-                gx = _conv(g1pre, y1, c3_1, IN_BNBWD, _pack(c1w, 1), None, g2pre, None, EPI_ADD, B, F, T)
+                gx = _conv(g1pre, y1, c3_1, IN_BNBWD, p1b, None, g2pre, None, EPI_ADD, B, F, T)
                 check(lib().sp_conv3x5_wgrad(ptr(x), None, IN_ID, ptr(g1pre), ptr(y1), ptr(c3_1), B, F, T,
                                              ptr(ws), ptr(gw1), s), "sp_conv3x5_wgrad")
                 # a conv bias feeding batch-statistics BatchNorm has an identically zero gradient

@@ -66,7 +66,12 @@ enum { EPI_NONE = 0, EPI_MASK = 1, EPI_ADD = 2 };
 // Weff[out = r][in = 16 half + 8 h + j][tap].  bwd_data: Weff[ci][co][kh][kw] = w[co][ci][2-kh][4-kw].
 // ---------------------------------------------------------------------------------------------
 __global__ void conv_pack_kernel(const float* __restrict__ w, int bwd_data, __hip_bfloat16* __restrict__ wpack) {
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (bwd_data == 2) {   // both layouts in one launch: forward in wpack[0:N], backward-data in wpack[N:2N]
+        if (i >= 2 * 15 * 2 * 64 * 8) return;
+        bwd_data = i >= 15 * 2 * 64 * 8;
+        if (bwd_data) { i -= 15 * 2 * 64 * 8; wpack += 15 * 2 * 64 * 8; }
+    }
     if (i >= 15 * 2 * 64 * 8) return;
     const int j = i & 7, lane = (i >> 3) & 63, half = (i >> 9) & 1, tap = i >> 10;
     const int r = lane & 31, h = lane >> 5;
@@ -471,13 +476,17 @@ __global__ __launch_bounds__(320) void conv3x5_wgrad_kernel(
     }
 }
 
-__global__ void conv_wgrad_unpack_kernel(const float* __restrict__ gwp, float* __restrict__ gw) {
+__global__ void conv_wgrad_unpack_kernel(float* __restrict__ gwp, float* __restrict__ gw) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;  // over [co][ci][kh][kw]
     if (i >= 32 * 32 * 15) return;
     const int tap = i % 15, ci = (i / 15) % 32, co = i / (15 * 32);
     float sum = 0.f;
 #pragma unroll
-    for (int c = 0; c < 8; ++c) sum += gwp[c * (15 * 32 * 32) + (tap * 32 + co) * 32 + ci];
+    for (int c = 0; c < 8; ++c) {
+        float* p = gwp + c * (15 * 32 * 32) + (tap * 32 + co) * 32 + ci;
+        sum += *p;
+        *p = 0.f;           // the workspace is handed back zeroed: the next launch needs no fill
+    }
     gw[i] += sum;
 }
 
@@ -826,7 +835,9 @@ typedef __hip_bfloat16 bf16;
 
 extern "C" int sp_conv_pack_w(const float* w, int bwd_data, void* wpack, void* stream) {
     SP_CHECK_ARG(w && wpack, "sp_conv_pack_w: null pointer");
-    hipLaunchKernelGGL(conv_pack_kernel, dim3(60), dim3(256), 0, (hipStream_t)stream, w, bwd_data, (bf16*)wpack);
+    SP_CHECK_ARG(bwd_data >= 0 && bwd_data <= 2, "sp_conv_pack_w: bwd_data %d (0 forward, 1 backward-data, 2 both)", bwd_data);
+    hipLaunchKernelGGL(conv_pack_kernel, dim3(bwd_data == 2 ? 120 : 60), dim3(256), 0, (hipStream_t)stream, w, bwd_data,
+                       (bf16*)wpack);
     return check_launch("conv_pack_kernel");
 }
 
@@ -866,8 +877,6 @@ extern "C" int sp_conv3x5_wgrad(const void* a_src, const float* a_coef, int a_mo
     SP_CHECK_ARG(a_src && g && y && g_coef && gwp_ws && gw, "sp_conv3x5_wgrad: null pointer");
     SP_CHECK_ARG(a_mode == IN_ID || (a_mode == IN_BNRELU && a_coef), "sp_conv3x5_wgrad: bad activation mode");
     hipStream_t s = (hipStream_t)stream;
-    hipError_t e = hipMemsetAsync(gwp_ws, 0, 8 * 15 * 32 * 32 * sizeof(float), s);
-    if (e != hipSuccess) return fail(SP_ELAUNCH, "sp_conv3x5_wgrad: %s", hipGetErrorString(e));
     const int fsplit = F >= 8 ? 2 : 1;
     dim3 grid((T + 63) / 64, B * fsplit), blk(320);
     if (a_mode == IN_ID)

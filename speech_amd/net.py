@@ -135,12 +135,17 @@ class SRU(nn.Module):
         masks = None
         drops = [c.dropout for c in self.rnn_lst]
         if self.training and any(p > 0 for p in drops):
-            # every layer's variational mask in three launches instead of three per layer
+            # every layer's variational mask at once instead of three launches per layer
             B, d2 = x.shape[1], self.rnn_lst[0].output_size
-            keep = getattr(self, "_keep", None)
-            if keep is None or keep.device != x.device or keep.shape[0] != len(drops):
-                keep = self._keep = torch.tensor([1.0 - p for p in drops], device=x.device).view(-1, 1, 1)
-            masks = torch.bernoulli(keep.expand(len(drops), B, d2)) / keep
+            pos = sorted({p for p in drops if p > 0})
+            if len(pos) == 1:      # one rate (the reference's case): scalar-probability kernel, in place
+                keep = 1.0 - pos[0]
+                masks = torch.empty((len(drops), B, d2), device=x.device).bernoulli_(keep).mul_(1.0 / keep)
+            else:
+                keep = getattr(self, "_keep", None)
+                if keep is None or keep.device != x.device or keep.shape[0] != len(drops):
+                    keep = self._keep = torch.tensor([1.0 - p for p in drops], device=x.device).view(-1, 1, 1)
+                masks = torch.bernoulli(keep.expand(len(drops), B, d2)) / keep
         for i, cell in enumerate(self.rnn_lst):
             m = masks[i] if masks is not None and drops[i] > 0 else None
             x = cell(x, m)

@@ -47,16 +47,19 @@ int sp_version(void);
  * fb[f*80+m], what torchaudio.functional.melscale_fbanks returns) into a device "plan"
  * (twiddles, window, band-limited filterbank tiles).  Done once; the plan is caller-owned.
  *
- * sp_melspec_fwd: wav = concatenated utterances (f32, [-1,1]); wav_offsets[B+1] (DEVICE int64,
+ * sp_melspec_fwd: wav = concatenated utterances (f32 in [-1,1]; or, with flags bit2, int16 PCM read
+ * as sample/32768 -- what torchaudio.load(normalize=True) gives the reference for 16-bit files, at
+ * half the bytes); wav_offsets[B+1] (DEVICE int64,
  * in samples) delimits them.  Utterance b has N_b = off[b+1]-off[b] samples (N_b > 200,
  * reflect padding needs it; the caller checks) and T_b = 1 + N_b/160 frames.  out is
  * [B, 80, T_max] f32 (= [B,1,80,T_max]); frames t >= T_b are written as 0.  masks: DEVICE
  * int32 [B][4] = (f0, fw, t0, tw) or NULL; rows [f0,f0+fw) and frames [t0,t0+tw) of utterance b
- * become 0.  flags: bit0 = natural log of (mel + 1e-6) (not reference behaviour; 0 = parity).
+ * become 0.  flags: bit0 = natural log of (mel + 1e-6) (not reference behaviour; 0 = parity);
+ * bit2 (value 4) = wav is int16.
  * --------------------------------------------------------------------------------------- */
 size_t sp_melspec_plan_bytes(void);
 int sp_melspec_plan(const float* fbank_host, void* plan_dev, void* stream);
-int sp_melspec_fwd(const float* wav, const int64_t* wav_offsets, int B, int T_max,
+int sp_melspec_fwd(const void* wav, const int64_t* wav_offsets, int B, int T_max,
                    const void* plan_dev, const int32_t* masks, int flags, float* out,
                    void* stream);
 

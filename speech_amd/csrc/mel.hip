@@ -55,8 +55,14 @@ using f32x4 = __attribute__((ext_vector_type(4))) float;
 // chip holds 3 waves per SIMD): every phase therefore issues all of its loads before its first use
 // (straight-line code, registers instead of occupancy), and the mel projection runs its A-operand
 // loads eight MFMAs ahead in a register ring.
+// S = sample type: float in [-1, 1], or int16_t PCM read as sample / 32768 (exact in f32: what
+// torchaudio.load(normalize=True) hands the reference for 16-bit files) -- half the bytes to read.
+__device__ __forceinline__ float pcm(const float* x, int i) { return x[i]; }
+__device__ __forceinline__ float pcm(const int16_t* x, int i) { return (float)x[i] * (1.f / 32768.f); }
+
+template <typename S>
 __global__ __launch_bounds__(64 * kWPB, 3) void melspec_kernel(
-    const float* __restrict__ wav, const int64_t* __restrict__ offs, int T_max,
+    const S* __restrict__ wav, const int64_t* __restrict__ offs, int T_max,
     const MelPlan* __restrict__ plan, const int32_t* __restrict__ masks, int flags,
     float* __restrict__ out) {
     __shared__ WaveLds s_lds[kWPB];
@@ -68,7 +74,7 @@ __global__ __launch_bounds__(64 * kWPB, 3) void melspec_kernel(
     const int64_t off = offs[b];
     const int N = (int)(offs[b + 1] - off);
     const int Tb = N > 0 ? 1 + N / kHop : 0;
-    const float* x = wav + off;
+    const S* x = wav + off;
     float* outb = out + (int64_t)b * kMels * T_max;
 
     if (t0 >= Tb) {  // pure padding: zeros
@@ -102,8 +108,8 @@ __global__ __launch_bounds__(64 * kWPB, 3) void melspec_kernel(
             if (interior) {
 #pragma unroll
                 for (int n1 = 0; n1 < 8; ++n1) {
-                    xs[p][2 * n1] = x[base + 50 * n1];
-                    xs[p][2 * n1 + 1] = x[base + 50 * n1 + 1];
+                    xs[p][2 * n1] = pcm(x, base + 50 * n1);
+                    xs[p][2 * n1 + 1] = pcm(x, base + 50 * n1 + 1);
                 }
             } else {
                 const bool live = t < Tb;
@@ -112,7 +118,7 @@ __global__ __launch_bounds__(64 * kWPB, 3) void melspec_kernel(
                     int i0 = reflect(base + 50 * n1, N), i1 = reflect(base + 50 * n1 + 1, N);
                     i0 = min(max(i0, 0), N - 1);
                     i1 = min(max(i1, 0), N - 1);
-                    const float v0 = x[i0], v1 = x[i1];
+                    const float v0 = pcm(x, i0), v1 = pcm(x, i1);
                     xs[p][2 * n1] = live ? v0 : 0.f;
                     xs[p][2 * n1 + 1] = live ? v1 : 0.f;
                 }
@@ -295,7 +301,7 @@ extern "C" int sp_melspec_plan(const float* fbank_host, void* plan_dev, void* st
     return SP_OK;
 }
 
-extern "C" int sp_melspec_fwd(const float* wav, const int64_t* wav_offsets, int B, int T_max,
+extern "C" int sp_melspec_fwd(const void* wav, const int64_t* wav_offsets, int B, int T_max,
                               const void* plan_dev, const int32_t* masks, int flags, float* out,
                               void* stream) {
     using namespace sp;
@@ -305,8 +311,13 @@ extern "C" int sp_melspec_fwd(const float* wav, const int64_t* wav_offsets, int 
     SP_CHECK_ARG(B <= 65535, "sp_melspec_fwd: B=%d exceeds grid limit", B);
     const int per_block = kF * kWPB;
     dim3 grid((T_max + per_block - 1) / per_block, B);
-    hipLaunchKernelGGL(melspec_kernel, grid, dim3(64 * kWPB), 0, reinterpret_cast<hipStream_t>(stream),
-                       wav, wav_offsets, T_max, reinterpret_cast<const MelPlan*>(plan_dev), masks,
-                       flags, out);
+    if (flags & 4)
+        hipLaunchKernelGGL((melspec_kernel<int16_t>), grid, dim3(64 * kWPB), 0, reinterpret_cast<hipStream_t>(stream),
+                           (const int16_t*)wav, wav_offsets, T_max, reinterpret_cast<const MelPlan*>(plan_dev), masks,
+                           flags, out);
+    else
+        hipLaunchKernelGGL((melspec_kernel<float>), grid, dim3(64 * kWPB), 0, reinterpret_cast<hipStream_t>(stream),
+                           (const float*)wav, wav_offsets, T_max, reinterpret_cast<const MelPlan*>(plan_dev), masks,
+                           flags, out);
     return check_launch("melspec_kernel");
 }

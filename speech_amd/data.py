@@ -10,6 +10,13 @@ utterance are zeroed.  The (start, width) draws are made on the host from torch'
 the order torchaudio makes them -- per utterance: rand()*15, rand()*(80 - value), rand()*35,
 rand()*(T_b - value) -- and handed to the kernel.
 """
+import gc
+import io
+import json
+import os
+import pickle
+import wave
+
 import numpy as np
 import torch
 
@@ -45,14 +52,25 @@ def draw_masks(frame_counts):
 
 
 def featurize(waveforms, augment=False, t_max=None, device=None):
-    """list of [1,N] / [N] waveforms (any device) -> [B,1,80,Tmax] on the GPU, one launch."""
+    """list of [1,N] / [N] waveforms (any device) -> [B,1,80,Tmax] on the GPU, one launch.  Waveforms that
+    are ALL int16 PCM (what load_audio returns for 16-bit files) go to the GPU as int16 -- half the bytes
+    over PCIe and out of HBM -- and the kernel reads sample / 32768, the value torchaudio.load(normalize=True)
+    gives the reference; anything else is converted to float32 first."""
     device = device or _device()
     flats = [w.reshape(-1) for w in waveforms]
     lens = [int(w.numel()) for w in flats]
     offs = torch.tensor(np.concatenate([[0], np.cumsum(lens)]), dtype=torch.int64)
-    flat = torch.cat([w.to(device=device, dtype=torch.float32, non_blocking=True) for w in flats])
+    if all(w.dtype == torch.int16 for w in flats):
+        flat = torch.cat([w.to(device=device, non_blocking=True) for w in flats])
+    else:
+        flat = torch.cat([_to_float(w).to(device=device, dtype=torch.float32, non_blocking=True) for w in flats])
     masks = draw_masks([ops.num_frames(n) for n in lens]) if augment else None
     return ops.melspec(flat, offs, t_max=t_max, masks=masks)
+
+
+def _to_float(w):
+    """int16 PCM -> float as torchaudio.load(normalize=True); other dtypes unchanged."""
+    return w.to(torch.float32) / 32768.0 if w.dtype == torch.int16 else w
 
 
 class _SpectrogramTransform:
@@ -103,6 +121,143 @@ class SortedDataset(torch.utils.data.Dataset):
 
     def get_clip(self, i):
         raise NotImplementedError
+
+
+# ------------------------------------------------------------------------------------------
+# Dataset / IO path (data.py:30-157): manifests of (path, n_samples) sorted by duration, LibriSpeech
+# transcript lookup, TV-style wav + txt pairs.  Audio decoding: the reference calls torchaudio.load;
+# here 16-bit PCM WAV is read with the standard library and handed on as RAW int16 (the GPU featuriser
+# scales it), other containers need `soundfile` if it is installed.
+# ------------------------------------------------------------------------------------------
+class _ManifestUnpickler(pickle.Unpickler):
+    """Manifests are pickled lists of (path, n_samples) tuples (data.py:31-32): plain containers only."""
+
+    def find_class(self, module, name):
+        raise pickle.UnpicklingError(f"manifest may hold only lists/tuples/str/numbers, found {module}.{name}")
+
+
+def load_manifest(dataset_path):
+    """[(path, n_samples), ...] from a .pkl (the reference's format) or .json manifest."""
+    if dataset_path.endswith(".json"):
+        with open(dataset_path) as f:
+            return [(str(p), n) for p, n in json.load(f)]
+    with open(dataset_path, "rb") as f:
+        return [(str(t[0]), t[1]) for t in _ManifestUnpickler(io.BytesIO(f.read())).load()]
+
+
+def get_librispeech_paths(dataset_path):
+    """data.py:30-33: (path, seconds) pairs."""
+    return [(p, n / SAMPLE_RATE) for p, n in load_manifest(dataset_path)]
+
+
+def load_audio(audio_path):
+    """-> (waveform [1, N], sample_rate).  16-bit PCM WAV: int16 samples, undivided (featurize / the
+    kernel apply the 1/32768 of torchaudio's normalize=True)."""
+    if audio_path.lower().endswith(".wav"):
+        with wave.open(audio_path, "rb") as f:
+            if f.getsampwidth() != 2:
+                raise ValueError(f"{audio_path}: only 16-bit PCM WAV is read natively")
+            nch, sr = f.getnchannels(), f.getframerate()
+            pcm = np.frombuffer(f.readframes(f.getnframes()), dtype="<i2").reshape(-1, nch).T.copy()
+        return torch.from_numpy(pcm), sr
+    try:
+        import soundfile
+    except ImportError as e:
+        raise RuntimeError(f"{audio_path}: decoding this container needs the soundfile package") from e
+    pcm, sr = soundfile.read(audio_path, dtype="int16", always_2d=True)
+    return torch.from_numpy(pcm.T.copy()), sr
+
+
+def get_librispeech_clip(audio_path):
+    """data.py:36-52: waveform + lower-cased transcript line of <speaker>-<chapter>.trans.txt."""
+    path, filename = os.path.split(audio_path)
+    fileid = filename.split(".")[0]
+    speaker_id, chapter_id, _ = fileid.split("-")
+    waveform, _ = load_audio(audio_path)
+    utterance = None
+    with open(os.path.join(path, speaker_id + "-" + chapter_id + ".trans.txt")) as f:
+        for line in f:
+            fileid_text, utt = line.strip().split(" ", 1)
+            if fileid == fileid_text:
+                utterance = utt
+                break
+    if utterance is None:
+        raise KeyError(f"{fileid} not in its chapter's .trans.txt")
+    return waveform, utterance.lower()
+
+
+def get_tv_clip(audio_path):
+    """data.py:55-60: waveform + the .txt next to the .wav."""
+    text_path = audio_path[:-4] + ".txt" if audio_path.endswith(".wav") else audio_path + ".txt"
+    waveform, _ = load_audio(audio_path)
+    with open(text_path) as f:
+        return waveform, f.read().strip()
+
+
+def _remap(path, root_map):
+    for old, new in root_map:
+        path = path.replace(old, new)
+    return path
+
+
+class SortedLibriSpeech(SortedDataset):
+    """data.py:105-115.  root_map replaces the reference's hard-coded "/data" -> "/hd1"."""
+
+    def __init__(self, dataset_path, batch_size, root_map=(("/data", "/hd1"),)):
+        super().__init__(batch_size)
+        assert dataset_path.endswith((".pkl", ".json"))
+        self.paths = [t[0] for t in get_librispeech_paths(dataset_path)]
+        if "train" in dataset_path:
+            self.paths = self.paths[:-1000]      # remove the longest clips
+        self.root_map = tuple(root_map)
+
+    def get_clip(self, i):
+        return get_librispeech_clip(_remap(self.paths[i], self.root_map))
+
+
+class SortedTV(SortedDataset):
+    """data.py:118-130: wav + txt pairs from several manifests; `device` picks the disk /hd<device+1>."""
+
+    def __init__(self, dataset_paths, batch_size, device, root_map=None):
+        super().__init__(batch_size)
+        hd = "/hd" + str(device + 1)
+        self.root_map = tuple(root_map) if root_map is not None else (("/data", hd), ("/hd1", hd))
+        for dataset_path in dataset_paths:
+            self.paths.extend(_remap(t[0], self.root_map) for t in load_manifest(dataset_path))
+
+    def get_clip(self, i):
+        return get_tv_clip(self.paths[i])
+
+
+class CombinedTVLibriSpeech(SortedDataset):
+    """data.py:133-157: LibriSpeech (minus its 2000 longest) and TV manifests merged and re-sorted by
+    duration; paths kept as one numpy bytes array (the reference does this to keep fork()ed DataLoader
+    workers from copying a Python list).  As in the reference, only the LibriSpeech manifest's second
+    field is divided by 16000: TV manifests merged here carry seconds."""
+
+    def __init__(self, librispeech_dataset_path, tv_dataset_paths, batch_size, device, root_map=None):
+        super().__init__(batch_size)
+        tuples = get_librispeech_paths(librispeech_dataset_path)[:-2000]
+        for dataset_path in tv_dataset_paths:
+            tuples.extend(load_manifest(dataset_path))
+        tuples = sorted(tuples, key=lambda t: t[1])
+        self.paths = np.array([t[0] for t in tuples]).astype(np.bytes_)
+        del tuples
+        gc.collect()
+        self.hd = "/hd" + str(device + 1)
+        self.root_map = root_map
+
+    def get_clip(self, i):
+        audio_path = str(self.paths[i], encoding="utf-8")
+        if self.root_map is not None:
+            audio_path = _remap(audio_path, self.root_map)
+        if "LibriSpeech" in audio_path:
+            return get_librispeech_clip(audio_path if self.root_map is not None else audio_path.replace("/data", self.hd))
+        if "clean" in audio_path:
+            return get_tv_clip(audio_path if self.root_map is not None else audio_path.replace("/hd1", self.hd))
+        if "gigaspeech" in audio_path:
+            return get_tv_clip(audio_path)
+        raise ValueError(f"{audio_path} not in datasets")
 
 
 class SyntheticSorted(SortedDataset):

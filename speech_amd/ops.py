@@ -71,13 +71,15 @@ def num_frames(n_samples):
 
 
 def melspec(wav, offsets, t_max=None, masks=None, flags=0, plan=None, out=None, offsets_host=None):
-    """wav: flat f32 device tensor of concatenated utterances; offsets: int64 [B+1] (device or
-    host) -> mel [B, 1, 80, T_max] f32.  masks: int32 [B,4] (f0, fw, t0, tw) or None.
+    """wav: flat f32 (or int16 PCM, read as sample / 32768) device tensor of concatenated utterances;
+    offsets: int64 [B+1] (device or host) -> mel [B, 1, 80, T_max] f32.  masks: int32 [B,4] (f0, fw, t0, tw) or None.
     offsets_host: the same offsets on the host, when the caller has them (a loader does): with device
     `offsets` alone the shapes have to be fetched back, which drains the stream once per call."""
     _need_cuda(wav, "wav")
-    if wav.dtype != torch.float32 or not wav.is_contiguous():
-        raise ValueError("wav must be a contiguous float32 tensor")
+    if wav.dtype not in (torch.float32, torch.int16) or not wav.is_contiguous():
+        raise ValueError("wav must be a contiguous float32 (or int16 PCM) tensor")
+    if wav.dtype == torch.int16:
+        flags |= 4           # samples are read as pcm / 32768
     if offsets_host is not None:
         offs_host = torch.as_tensor(offsets_host, dtype=torch.int64)
         if offs_host.is_cuda or offs_host.numel() != offsets.numel():

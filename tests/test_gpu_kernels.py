@@ -586,6 +586,29 @@ def test_ctc_grad_in_bf16_is_the_rounded_f32_grad(cuda, time_major, V):
     assert torch.equal(g16, g32.to(torch.bfloat16))
 
 
+def test_mel_int16_pcm_equals_float_path(cuda):
+    """int16 PCM input (flags bit 2): bit-identical to featurising pcm / 32768 as float32 -- the value
+    torchaudio.load(normalize=True) gives the reference -- ragged batch, masks, padding included."""
+    from speech_amd import data, ops
+    g = torch.Generator().manual_seed(11)
+    lens = [5000, 16000, 12345, 801]
+    pcm = [torch.randint(-32768, 32768, (1, n), generator=g, dtype=torch.int32).to(torch.int16) for n in lens]
+    offs = torch.tensor([0] + list(np.cumsum(lens)), dtype=torch.int64)
+    masks = torch.tensor([[3, 10, 5, 20], [70, 10, 0, 0], [0, 0, 60, 17], [10, 5, 2, 3]], dtype=torch.int32)
+    flat16 = torch.cat([w.reshape(-1) for w in pcm]).to(cuda)
+    flat32 = flat16.to(torch.float32) / 32768.0
+    a = ops.melspec(flat16, offs, masks=masks)
+    b = ops.melspec(flat32, offs, masks=masks)
+    assert a.shape == (4, 1, 80, 101) and torch.equal(a, b)
+    # through the collate path: a list of int16 clips stays int16 up to the kernel
+    c = data.featurize(pcm)
+    d = data.featurize([w.float() / 32768.0 for w in pcm])
+    assert torch.equal(c, d)
+    # a mixed list falls back to float
+    e = data.featurize([pcm[0], pcm[1].float() / 32768.0])
+    assert torch.equal(e, data.featurize([pcm[0].float() / 32768.0, pcm[1].float() / 32768.0]))
+
+
 def test_conv_fused_bn_sums_are_reproducible(cuda):
     """The statistics fused into the convolution epilogue equal sp_bn_stats of its output, and two
     launches give the same BITS (per-workgroup partials summed in a fixed order, no float atomics)."""

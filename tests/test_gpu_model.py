@@ -296,3 +296,39 @@ def test_fused_head_matches_classifier_then_ctc(cuda, dtype):
         conv = k.startswith("cnn") or k.startswith("resnet")
         tol = 2e-2 if dtype == torch.bfloat16 else (5e-3 if conv else 1e-5)
         assert float((a - b).abs().max()) <= tol * float(a.abs().max()) + 1e-7, k
+
+
+def test_wav_dataset_to_train_step(cuda, tmp_path):
+    """The IO path end to end: 16-bit WAV files + transcripts on disk -> SortedTV -> DataLoader ->
+    collate_fn (int16 PCM straight into the fused frontend) -> train_step; the features equal the CPU
+    oracle's on the same samples."""
+    import pickle
+    import wave
+    from speech_amd import data
+    from speech_amd.train import FlatAdam, train_step
+    rs = np.random.RandomState(3)
+    entries = []
+    for k, n in enumerate([6400, 7000, 8000, 8123]):
+        p = tmp_path / f"clip{k}.wav"
+        with wave.open(str(p), "wb") as f:
+            f.setnchannels(1); f.setsampwidth(2); f.setframerate(16000)
+            f.writeframes((rs.randn(n) * 3000).clip(-32768, 32767).astype("<i2").tobytes())
+        (tmp_path / f"clip{k}.txt").write_text("hello world" if k % 2 else "a test")
+        entries.append((str(p), n))
+    (tmp_path / "m.pkl").write_bytes(pickle.dumps(entries))
+    ds = data.SortedTV([str(tmp_path / "m.pkl")], 2, 0, root_map=())
+    loader = torch.utils.data.DataLoader(ds, batch_size=None, shuffle=False,
+                                         collate_fn=lambda b: data.collate_fn(b, "valid"))
+    batches = list(loader)
+    assert len(batches) == 2
+    spec, labels, ll = batches[1]
+    assert spec.is_cuda and tuple(spec.shape) == (2, 1, 80, 1 + 8123 // 160) and ll.tolist() == [6, 11]
+    ref = omel.collate([w.float() / 32768.0 for w, _ in ds[1]])
+    assert float((spec.cpu() - ref).abs().max()) <= 1e-4 * float(ref.abs().max())
+    m = _small_model(cuda, torch.bfloat16)
+    m.train()
+    opt = FlatAdam(m.parameters(), lr=1e-3)
+    l0 = float(train_step(m, opt, spec, labels.to(cuda), ll.to(cuda), 2.0))
+    for _ in range(5):
+        l1 = float(train_step(m, opt, spec, labels.to(cuda), ll.to(cuda), 2.0))
+    assert np.isfinite(l1) and l1 < l0

@@ -11,7 +11,6 @@ the order torchaudio makes them -- per utterance: rand()*15, rand()*(80 - value)
 rand()*(T_b - value) -- and handed to the kernel.
 """
 import gc
-import io
 import json
 import os
 import pickle
@@ -142,7 +141,7 @@ def load_manifest(dataset_path):
         with open(dataset_path) as f:
             return [(str(p), n) for p, n in json.load(f)]
     with open(dataset_path, "rb") as f:
-        return [(str(t[0]), t[1]) for t in _ManifestUnpickler(io.BytesIO(f.read())).load()]
+        return [(str(t[0]), t[1]) for t in _ManifestUnpickler(f).load()]
 
 
 def get_librispeech_paths(dataset_path):

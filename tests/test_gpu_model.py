@@ -332,3 +332,39 @@ def test_wav_dataset_to_train_step(cuda, tmp_path):
     for _ in range(5):
         l1 = float(train_step(m, opt, spec, labels.to(cuda), ll.to(cuda), 2.0))
     assert np.isfinite(l1) and l1 < l0
+
+
+def test_filter_alignments_workload(cuda, tmp_path, monkeypatch):
+    """scripts/tv/filter_alignments.py mirror: manifest -> MetaTV (score filter, > 6 s clips silenced) ->
+    batched inference + GPU greedy decode -> first/last-word rule."""
+    import pickle
+    import wave
+    from speech_amd.scripts import filter_alignments as fa
+    rs = np.random.RandomState(5)
+    entries = []
+    for k, (n, score, txt) in enumerate([(8000, 0.1, "hello big world"), (9000, 0.5, "dropped by score"),
+                                         (7000, 0.2, ""), (16000 * 7, 0.0, "too long clip"), (6000, 0.3, "one")]):
+        p = tmp_path / f"c{k}.wav"
+        with wave.open(str(p), "wb") as f:
+            f.setnchannels(1); f.setsampwidth(2); f.setframerate(16000)
+            f.writeframes((rs.randn(n) * 2000).astype("<i2").tobytes())
+        if k != 2:
+            (tmp_path / f"c{k}.txt").write_text(txt)
+        entries.append((str(p), score, n / 16000))
+    (tmp_path / "manifest.pkl").write_bytes(pickle.dumps(entries))
+    ds = fa.MetaTV(str(tmp_path / "manifest.pkl"), 4, root_map=())
+    assert [m[1] for m in ds.paths] == [0.3, 0.2, 0.1, 0.0]                 # sorted by duration, score <= 0.3 kept
+    clips = ds[0]
+    assert clips[3][0].shape[1] == 16000 and float(clips[3][0].abs().max()) == 0     # the 7 s clip is silenced
+    assert clips[1][1] is None                                                         # no transcript file
+    spec, transcripts, manifests = fa.collate_fn(clips)
+    assert spec.is_cuda and spec.shape[0] == 4 and transcripts[2] == "hello big world"
+    # the rule, independent of the model
+    assert fa.keep_entry("hello small world", "hello big world") and not fa.keep_entry("hello", "hello world")
+    assert not fa.keep_entry("hello big word", "hello big world") and not fa.keep_entry("a b", None)
+    # end to end with a model whose decoder output is pinned
+    model = _small_model(cuda, torch.bfloat16).eval()
+    monkeypatch.setattr(fa.decoder, "greedy_decode", lambda out: ["one"] + ["hello there world"] * (out.shape[0] - 1))
+    loader = torch.utils.data.DataLoader(ds, batch_size=None, collate_fn=fa.collate_fn, shuffle=False)
+    kept = fa.filter_files(model, loader)
+    assert [m[2] for m in kept] == [0.5]                                               # only "hello big world"

@@ -112,7 +112,8 @@ int sp_edit_distance(const int32_t* a, int na, const int32_t* b, int nb);
  *   mask [B][2][d] f32 or NULL   variational dropout mask on the cell state (already / (1-p))
  *   h   [T*B][2][d]      output, act dtype;   c [T*B][2][d] cell states kept for the backward, act
  *                        dtype too (the recurrence runs in f32 registers; the sru package saves c in
- *                        the activation dtype as well)
+ *                        the activation dtype as well).  sp_sru_fwd accepts c == NULL (inference:
+ *                        nothing is kept, a third of the forward's stores)
  * dtype = element type of U, xres, h, and of gh/gU/gxres in the backward.
  * Backward: gh is d loss / d h.  Writes gU (same layout as U), gxres ([T*B][2][d], k == 3
  * only, else may be NULL), and ACCUMULATES into gwc/gbias ([2][2][d] f32, caller zeroes).

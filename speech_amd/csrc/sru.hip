@@ -43,7 +43,7 @@ __global__ __launch_bounds__(64) void sru_fwd_kernel(
     const T* Ub = U + (int64_t)b * K * D2 + cd;
     const T* Xb = (K == 3) ? xres + (int64_t)b * D2 + cd : nullptr;
     T* hb = h + (int64_t)b * D2 + cd;
-    float* cb = cst + (int64_t)b * D2 + cd;
+    float* cb = cst ? cst + (int64_t)b * D2 + cd : nullptr;     // NULL: inference, nothing kept for a backward
 
     T a0[UN], a1[UN], a2[UN], a3[UN];
     T b0[UN], b1[UN], b2[UN], b3[UN];
@@ -77,7 +77,7 @@ __global__ __launch_bounds__(64) void sru_fwd_kernel(
                 c = v0 + (c - v0) * f;
                 const float hv = (c * m - x) * r + x;
                 Elem<T>::st(hb + t * hstep, hv);
-                cb[t * hstep] = c;
+                if (cb) cb[t * hstep] = c;
             }
         }
     };
@@ -298,7 +298,7 @@ __global__ __launch_bounds__(192) void sru_fwd_split_kernel(
     const float nvr = -kL2e * wc[D2 + cd], nbr = -kL2e * bias[D2 + cd];
     const float m = mask ? mask[(int64_t)b * D2 + cd] : 1.f;
     __hip_bfloat16* hb = h + (int64_t)b * D2 + cd0;
-    __hip_bfloat16* cb = cst + (int64_t)b * D2 + cd0;
+    __hip_bfloat16* cb = cst ? cst + (int64_t)b * D2 + cd0 : nullptr;   // NULL: inference, c is not kept
     float cprev = 0.f;
     for (int j = 0; j <= nch; ++j) {
         __builtin_amdgcn_s_barrier();
@@ -329,7 +329,7 @@ __global__ __launch_bounds__(192) void sru_fwd_split_kernel(
                 if (i < Tn) {
                     const int64_t t = dir ? Tn - 1 - i : i;
                     *reinterpret_cast<uint4*>(hb + t * hstep + p8 * 8) = *reinterpret_cast<const uint4*>(&htile[s][p8 * 8]);
-                    *reinterpret_cast<uint4*>(cb + t * hstep + p8 * 8) = *reinterpret_cast<const uint4*>(&ctile[s][p8 * 8]);
+                    if (cb) *reinterpret_cast<uint4*>(cb + t * hstep + p8 * 8) = *reinterpret_cast<const uint4*>(&ctile[s][p8 * 8]);
                 }
             }
             __builtin_amdgcn_wave_barrier();
@@ -610,7 +610,7 @@ extern "C" int sp_sru_fwd(const void* U, const void* xres, const float* wc, cons
     int rc = sru_check("sp_sru_fwd", T, B, d, k, dtype);
     if (rc) return rc;
     if (T == 0 || B == 0) return SP_OK;
-    SP_CHECK_ARG(U && wc && bias && h && c && (k == 4 || xres), "sp_sru_fwd: null pointer");
+    SP_CHECK_ARG(U && wc && bias && h && (k == 4 || xres), "sp_sru_fwd: null pointer");
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
     if (dtype == SP_F32) return sru_fwd_t<float>(U, xres, wc, bias, mask, T, B, d, k, h, (float*)c, s);
     {   // role-split path (any d % 64 == 0)

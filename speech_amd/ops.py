@@ -230,10 +230,11 @@ def edit_distance(a, b):
 # ------------------------------------------------------------------------------------------
 # SRU recurrence (net.py:61-72)
 # ------------------------------------------------------------------------------------------
-def sru_fwd(U, xres, wc, bias, mask, T, B, d, k):
+def sru_fwd(U, xres, wc, bias, mask, T, B, d, k, keep_c=True):
+    """-> (h, c); keep_c=False (inference) skips the cell-state store and returns c = None."""
     _need_cuda(U, "U")
     h = torch.empty((T, B, 2 * d), dtype=U.dtype, device=U.device)
-    c = torch.empty((T, B, 2 * d), dtype=U.dtype, device=U.device)
+    c = torch.empty((T, B, 2 * d), dtype=U.dtype, device=U.device) if keep_c else None
     with torch.cuda.device(U.device):
         check(lib().sp_sru_fwd(ptr(U), ptr(xres), ptr(wc), ptr(bias), ptr(mask), T, B, d, k,
                                _lib.dtype_code(U), ptr(h), ptr(c), stream_ptr()), "sp_sru_fwd")
@@ -566,17 +567,22 @@ class _SRULayerFn(torch.autograd.Function):
         pad = 64 if own and (n_in * x.element_size()) % 1024 == 0 else 0
         xn, mean, rstd = layernorm_fwd(x2, g32, b32, eps, pad)
         w32 = weight.detach().float().contiguous()
-        if own:      # W^T [N][n_in] for the forward (own kernel), W [n_in][N] for the data gradient
+        train = any(ctx.needs_input_grad)      # False under no_grad: nothing is kept for a backward
+        if own and train:      # W^T [N][n_in] for the forward (own kernel), W [n_in][N] for the data gradient
             wkt, wk = sru_pack_wt(w32, d, k, C, x.dtype, pad, both=True)
             U = gemm_nt(xn, wkt)
             del wkt
+        elif own:
+            wk = None
+            U = gemm_nt(xn, sru_pack_wt(w32, d, k, C, x.dtype, pad))
         else:        # wk holds W [n_in][N]
             wk = sru_pack_w(w32, d, k, C, x.dtype)
             U = torch.mm(xn, wk)
         wc32, bs32 = wc.detach().float().contiguous(), bias.detach().float().contiguous()
         xr = x2 if k == 3 else None
-        h, c = sru_fwd(U, xr, wc32, bs32, mask, T, B, d, k)
-        ctx.save_for_backward(x2, xn, mean, rstd, g32, wk, U, wc32, bs32, mask, c)
+        h, c = sru_fwd(U, xr, wc32, bs32, mask, T, B, d, k, keep_c=train)
+        if train:
+            ctx.save_for_backward(x2, xn, mean, rstd, g32, wk, U, wc32, bs32, mask, c)
         ctx.dims = (T, B, d, k, n_in, C)
         ctx.pdt = (ln_w.dtype, ln_b.dtype, weight.dtype, wc.dtype, bias.dtype)
         ctx.params = (ln_w, ln_b, weight, wc, bias)

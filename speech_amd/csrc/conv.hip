@@ -493,40 +493,83 @@ __global__ void conv_wgrad_unpack_kernel(float* __restrict__ gwp, float* __restr
 // ---------------------------------------------------------------------------------------------
 // stem: Conv2d(1, 32, 3, stride 2, pad 1) on the f32 spectrogram [B][Fin][Tin]
 // ---------------------------------------------------------------------------------------------
+// Thread = (position t, channel group ch4 = tid & 3).  The four lanes of a position share its input
+// taps: each lane loads one tap column (branch-free: clamped index, zeroed by a select when it falls
+// in the padding) and the quad exchanges them with DPP broadcasts.
+constexpr int kStemRows = 4;   // output rows per forward work item
+
+template <int K>
+__device__ __forceinline__ float quad_bcast(float v) {   // lane K of every aligned group of four
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), K * 0x55, 0xf, 0xf, true));
+}
+
+__device__ __forceinline__ float stem_tap(const float* __restrict__ sb, int fi, int Fin, int Tin, int tic, bool tok) {
+    const bool rowok = fi >= 0 && fi < Fin;
+    const float v = sb[(int64_t)min(max(fi, 0), Fin - 1) * Tin + tic];
+    return (rowok && tok) ? v : 0.f;
+}
+
+// The 72 weights and 8 biases of a thread's 8 output channels stay in registers; the workgroup is
+// persistent over work items = (utterance, kStemRows output rows, 64 positions) and requests the next
+// item's input taps before it computes the current one; a wave's store writes 1 KB of contiguous output.
 __global__ __launch_bounds__(256) void stem_fwd_kernel(const float* __restrict__ spec,
                                                        const float* __restrict__ w,
                                                        const float* __restrict__ bias, int B, int Fin,
                                                        int Tin, int F, int T,
                                                        __hip_bfloat16* __restrict__ out) {
-    __shared__ __attribute__((aligned(16))) float sw[9 * 32 + 32];  // [tap][co], then bias
-    for (int i = threadIdx.x; i < 288; i += 256) sw[(i % 9) * 32 + i / 9] = w[i];  // w is [co][9]
-    if (threadIdx.x < 32) sw[288 + threadIdx.x] = bias[threadIdx.x];
-    __syncthreads();
-    const int64_t n = (int64_t)B * F * T;
-    for (int64_t p = (int64_t)blockIdx.x * 256 + threadIdx.x; p < n; p += (int64_t)gridDim.x * 256) {
-        const int t = (int)(p % T);
-        const int64_t bf = p / T;
-        const int f = (int)(bf % F), b = (int)(bf / F);
-        float x[9];
+    const int ch4 = threadIdx.x & 3, tl = threadIdx.x >> 2, kw = min(ch4, 2);
+    float wr[72], bs[8];   // w is [co][9]: this thread's 8 channels are 72 contiguous floats
 #pragma unroll
-        for (int kh = 0; kh < 3; ++kh)
+    for (int i = 0; i < 18; ++i) {
+        const float4 v = *reinterpret_cast<const float4*>(w + ch4 * 72 + i * 4);
+        wr[i * 4] = v.x; wr[i * 4 + 1] = v.y; wr[i * 4 + 2] = v.z; wr[i * 4 + 3] = v.w;
+    }
 #pragma unroll
-            for (int kw = 0; kw < 3; ++kw) {
-                const int fi = 2 * f - 1 + kh, ti = 2 * t - 1 + kw;
-                x[kh * 3 + kw] = (fi >= 0 && fi < Fin && ti >= 0 && ti < Tin)
-                                     ? spec[((int64_t)b * Fin + fi) * Tin + ti] : 0.f;
-            }
+    for (int j = 0; j < 8; ++j) bs[j] = bias[ch4 * 8 + j];
+    const int fgroups = (F + kStemRows - 1) / kStemRows, nch = (T + 63) / 64;
+    const int items = B * fgroups * nch;
+    constexpr int NR = 2 * kStemRows + 1;   // input rows under kStemRows output rows
+    auto load = [&](int it, float (&v)[NR]) {
+        const int bf = it / nch, tc = it - bf * nch;
+        const int b = bf / fgroups, f0 = (bf - b * fgroups) * kStemRows;
+        const int ti = 2 * min(tc * 64 + tl, T - 1) - 1 + kw;
+        const bool tok = ti >= 0 && ti < Tin;
+        const int tic = min(max(ti, 0), Tin - 1);
+        const float* sb = spec + (int64_t)b * Fin * Tin;
 #pragma unroll
-        for (int c8 = 0; c8 < 4; ++c8) {
+        for (int i = 0; i < NR; ++i) v[i] = stem_tap(sb, 2 * f0 - 1 + i, Fin, Tin, tic, tok);
+    };
+    float cur[NR], nxt[NR];
+    int it = blockIdx.x;
+    if (it < items) load(it, cur);
+    for (; it < items; it += gridDim.x) {
+        const int itn = it + gridDim.x;
+        if (itn < items) load(itn, nxt);
+        const int bf = it / nch, tc = it - bf * nch;
+        const int b = bf / fgroups, f0 = (bf - b * fgroups) * kStemRows;
+        const int t = tc * 64 + tl;
+        float x[NR][3];
+#pragma unroll
+        for (int i = 0; i < NR; ++i) {
+            x[i][0] = quad_bcast<0>(cur[i]);
+            x[i][1] = quad_bcast<1>(cur[i]);
+            x[i][2] = quad_bcast<2>(cur[i]);
+        }
+#pragma unroll
+        for (int fr = 0; fr < kStemRows; ++fr) {
+            const int f = f0 + fr;
             float o[8];
 #pragma unroll
-            for (int j = 0; j < 8; ++j) o[j] = sw[288 + c8 * 8 + j];
+            for (int j = 0; j < 8; ++j) {
+                o[j] = bs[j];
 #pragma unroll
-            for (int tap = 0; tap < 9; ++tap)
-#pragma unroll
-                for (int j = 0; j < 8; ++j) o[j] += sw[tap * 32 + c8 * 8 + j] * x[tap];
-            *reinterpret_cast<uint4*>(out + p * kC + c8 * 8) = pack8(o);
+                for (int tap = 0; tap < 9; ++tap) o[j] += wr[j * 9 + tap] * x[2 * fr + tap / 3][tap % 3];
+            }
+            if (f < F && t < T)
+                *reinterpret_cast<uint4*>(out + (((int64_t)b * F + f) * T + t) * kC + ch4 * 8) = pack8(o);
         }
+#pragma unroll
+        for (int i = 0; i < NR; ++i) cur[i] = nxt[i];
     }
 }
 
@@ -539,35 +582,73 @@ __device__ __forceinline__ void reduce_ch4(float (&v)[NV]) {
         for (int i = 0; i < NV; ++i) v[i] += __shfl_xor(v[i], o);
 }
 
-// each thread owns one 16-byte chunk (8 channels, group tid & 3) of a position
-__global__ __launch_bounds__(256) void stem_bwd_kernel(const float* __restrict__ spec,
+// Each thread owns one 16-byte chunk (8 channels, group tid & 3) of a position and 80 accumulators.
+// Work items = (output row (b, f), chunk of 64 positions), walked by groups of four waves; a
+// workgroup holds kStemBwdGroups of them so that few workgroups finish in the 320 float atomics that
+// end the kernel (they serialise per address: ~20 ns each).  The loop is software-pipelined: the
+// loads of the next two items are requested before the current two are multiplied; lane ch4 of a
+// position loads input row min(ch4, 2) and the quad exchanges the taps with DPP broadcasts.
+constexpr int kStemBwdGroups = 3;
+
+__global__ __launch_bounds__(256 * kStemBwdGroups) void stem_bwd_kernel(const float* __restrict__ spec,
                                                        const __hip_bfloat16* __restrict__ gout, int B,
                                                        int Fin, int Tin, int F, int T,
                                                        float* __restrict__ gw, float* __restrict__ gbias) {
-    __shared__ float red[4][4][80];
-    const int ch4 = threadIdx.x & 3;
+    constexpr int NW = 4 * kStemBwdGroups;
+    __shared__ float red[NW][4][80];
+    const int ch4 = threadIdx.x & 3, tl = (threadIdx.x & 255) >> 2, kh = min(ch4, 2);
+    const int group = blockIdx.x * kStemBwdGroups + (threadIdx.x >> 8), ngroups = gridDim.x * kStemBwdGroups;
     float acc[80];
 #pragma unroll
     for (int i = 0; i < 80; ++i) acc[i] = 0.f;
-    const int64_t n = (int64_t)B * F * T;
-    for (int64_t p = ((int64_t)blockIdx.x * 256 + threadIdx.x) >> 2; p < n; p += ((int64_t)gridDim.x * 256) >> 2) {
-        const int t = (int)(p % T);
-        const int64_t bf = p / T;
-        const int f = (int)(bf % F), b = (int)(bf / F);
-        float gch[8];
-        unpack8(*reinterpret_cast<const uint4*>(gout + p * kC + ch4 * 8), gch);
+    const int nch = (T + 63) / 64, items = B * F * nch;
+    auto load = [&](int it, uint4& gr, float (&v)[3]) {
+        const int itc = min(it, items - 1);
+        const int row = itc / nch, tt = (itc - row * nch) * 64 + tl;
+        const bool ok = it < items && tt < T;
+        const int t = min(tt, T - 1);
+        const int b = row / F, f = row - b * F;
+        const float* sb = spec + (int64_t)b * Fin * Tin;
+        gr = *reinterpret_cast<const uint4*>(gout + ((int64_t)row * T + t) * kC + ch4 * 8);
+        if (!ok) gr = make_uint4(0, 0, 0, 0);   // past the end: zero gradient
+        const int ti0 = 2 * t - 1;
+        v[0] = stem_tap(sb, 2 * f - 1 + kh, Fin, Tin, max(ti0, 0), ti0 >= 0);
+        v[1] = stem_tap(sb, 2 * f - 1 + kh, Fin, Tin, ti0 + 1, true);               // 2 t <= Tin - 1 always
+        v[2] = stem_tap(sb, 2 * f - 1 + kh, Fin, Tin, min(ti0 + 2, Tin - 1), ti0 + 2 < Tin);
+    };
+    auto accum = [&](const uint4& gr, const float (&v)[3]) {
+        float gch[8], x[9];
+        unpack8(gr, gch);
 #pragma unroll
-        for (int kh = 0; kh < 3; ++kh)
+        for (int k = 0; k < 3; ++k) {
+            x[k] = quad_bcast<0>(v[k]);
+            x[3 + k] = quad_bcast<1>(v[k]);
+            x[6 + k] = quad_bcast<2>(v[k]);
+        }
 #pragma unroll
-            for (int kw = 0; kw < 3; ++kw) {
-                const int fi = 2 * f - 1 + kh, ti = 2 * t - 1 + kw;
-                const float x = (fi >= 0 && fi < Fin && ti >= 0 && ti < Tin)
-                                    ? spec[((int64_t)b * Fin + fi) * Tin + ti] : 0.f;
+        for (int tap = 0; tap < 9; ++tap)
 #pragma unroll
-                for (int j = 0; j < 8; ++j) acc[j * 9 + kh * 3 + kw] += gch[j] * x;
-            }
+            for (int j = 0; j < 8; ++j) acc[j * 9 + tap] += gch[j] * x[tap];
 #pragma unroll
         for (int j = 0; j < 8; ++j) acc[72 + j] += gch[j];
+    };
+    constexpr int NI = 2;
+    uint4 gr[NI], gn[NI];
+    float v[NI][3], vn[NI][3];
+    int it = group;
+#pragma unroll
+    for (int u = 0; u < NI; ++u) load(it + u * ngroups, gr[u], v[u]);
+    for (; it < items; it += NI * ngroups) {
+#pragma unroll
+        for (int u = 0; u < NI; ++u) load(it + (NI + u) * ngroups, gn[u], vn[u]);
+#pragma unroll
+        for (int u = 0; u < NI; ++u) accum(gr[u], v[u]);
+#pragma unroll
+        for (int u = 0; u < NI; ++u) {
+            gr[u] = gn[u];
+#pragma unroll
+            for (int k = 0; k < 3; ++k) v[u][k] = vn[u][k];
+        }
     }
     reduce_ch4<80>(acc);
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -576,9 +657,11 @@ __global__ __launch_bounds__(256) void stem_bwd_kernel(const float* __restrict__
         for (int i = 0; i < 80; ++i) red[wave][lane][i] = acc[i];
     }
     __syncthreads();
-    for (int i = threadIdx.x; i < 320; i += 256) {
+    for (int i = threadIdx.x; i < 320; i += blockDim.x) {
         const int c4 = i / 80, k = i % 80;
-        const float s = red[0][c4][k] + red[1][c4][k] + red[2][c4][k] + red[3][c4][k];
+        float s = 0.f;
+#pragma unroll
+        for (int wv = 0; wv < NW; ++wv) s += red[wv][c4][k];
         if (k < 72) atomicAdd(gw + (c4 * 8 + k / 9) * 9 + k % 9, s);
         else atomicAdd(gbias + c4 * 8 + (k - 72), s);
     }
@@ -896,7 +979,10 @@ extern "C" int sp_conv_stem_fwd(const float* spec, const float* w, const float* 
     SP_CHECK_ARG(B >= 1 && Fin >= 1 && Tin >= 1, "sp_conv_stem_fwd: bad shape");
     SP_CHECK_ARG(spec && w && bias && out, "sp_conv_stem_fwd: null pointer");
     const int F = (Fin - 1) / 2 + 1, T = (Tin - 1) / 2 + 1;
-    hipLaunchKernelGGL(stem_fwd_kernel, dim3(stream_blocks((int64_t)B * F * T)), dim3(256), 0,
+    const int64_t items = (int64_t)B * ((F + kStemRows - 1) / kStemRows) * ((T + 63) / 64);
+    SP_CHECK_ARG(items < ((int64_t)1 << 30), "sp_conv_stem_fwd: shape exceeds grid limits");
+    const int blocks = items < 768 ? (int)items : 768;   // persistent: three workgroups per CU
+    hipLaunchKernelGGL(stem_fwd_kernel, dim3(blocks), dim3(256), 0,
                        (hipStream_t)stream, spec, w, bias, B, Fin, Tin, F, T, (bf16*)out);
     return check_launch("stem_fwd_kernel");
 }
@@ -906,9 +992,11 @@ extern "C" int sp_conv_stem_bwd(const float* spec, const void* gout, int B, int 
     SP_CHECK_ARG(B >= 1 && Fin >= 1 && Tin >= 1, "sp_conv_stem_bwd: bad shape");
     SP_CHECK_ARG(spec && gout && gw && gbias, "sp_conv_stem_bwd: null pointer");
     const int F = (Fin - 1) / 2 + 1, T = (Tin - 1) / 2 + 1;
-    int blocks = stream_blocks((int64_t)B * F * T * 4);
-    if (blocks > 512) blocks = 512;
-    hipLaunchKernelGGL(stem_bwd_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, spec,
+    const int64_t items = (int64_t)B * F * ((T + 63) / 64);
+    SP_CHECK_ARG(items < ((int64_t)1 << 30), "sp_conv_stem_bwd: shape exceeds grid limits");
+    int blocks = (int)((items + kStemBwdGroups - 1) / kStemBwdGroups);
+    if (blocks > 256) blocks = 256;   // one workgroup of twelve waves per CU
+    hipLaunchKernelGGL(stem_bwd_kernel, dim3(blocks), dim3(256 * kStemBwdGroups), 0, (hipStream_t)stream, spec,
                        (const bf16*)gout, B, Fin, Tin, F, T, gw, gbias);
     return check_launch("stem_bwd_kernel");
 }

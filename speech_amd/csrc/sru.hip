@@ -361,16 +361,17 @@ __global__ __launch_bounds__(256) void sru_bwd_split_kernel(
     float* __restrict__ gbias) {
     constexpr int CH = 4, R = 12, ROW = 1024;   // (R-2) chunks = 40 DMA ops = 35 KB in flight per workgroup
     __shared__ __attribute__((aligned(16))) unsigned char ring[R * CH * ROW];            // 48 KB
-    __shared__ float sq[2][CH][64];                                                       // f-side -> r-side
-    __shared__ float sA[3][CH][64], sOmf[3][CH][64], sKap[3][CH][64], sKcp[3][CH][64];    // f-side -> chain
-    __shared__ float sG[2][CH][64], sBv[2][CH][64];                                       // r-side -> chain
+    __shared__ __attribute__((aligned(16))) float sq[2][CH][64];                          // f-side -> r-side
+    __shared__ __attribute__((aligned(16))) float sA[3][CH][64], sOmf[3][CH][64], sKap[3][CH][64], sKcp[3][CH][64];   // f-side -> chain
+    __shared__ __attribute__((aligned(16))) float sG[2][CH][64], sBv[2][CH][64];          // r-side -> chain
     __shared__ __attribute__((aligned(16))) unsigned short tg[2][2][CH][64];              // chain -> f-side: g0 | df
     __shared__ __attribute__((aligned(16))) unsigned short tr[2][CH][64];                 // r-side: dr | gx
     // Measured placement (tools/ubench/hwid.hip): workgroups b and b+256 share a CU, the first one's waves
-    // 0..3 sit on SIMDs 0,2,1,3 and the second one's on 2,1,3,0.  Rotating the second one's roles by
-    // three puts loader+r-side, r-side+loader, f-side+chain, chain+f-side on the four SIMDs.
-    const int rot = ((blockIdx.x >> 8) & 1) * 3;
-    const int wave = ((threadIdx.x >> 6) + rot) & 3, lane = threadIdx.x & 63;
+    // 0..3 sit on SIMDs 0,2,1,3 and the second one's on 2,1,3,0.  The second workgroup's roles are
+    // permuted so that the SIMDs carry loader+f-side, f-side+loader, r-side+chain, chain+r-side: the two
+    // heaviest roles (f-side, r-side) never share a SIMD and the f-side gets the lightest partner.
+    const int w0 = threadIdx.x >> 6;
+    const int wave = ((blockIdx.x >> 8) & 1) ? ((4 - w0) & 3) : w0, lane = threadIdx.x & 63;
     const int D2 = 2 * d;
     const int col0 = blockIdx.x * 64;
     const int b = col0 / D2, cd0 = col0 - b * D2, dir = cd0 / d;
@@ -400,17 +401,21 @@ __global__ __launch_bounds__(256) void sru_bwd_split_kernel(
             base = reinterpret_cast<const char*>(cst + (int64_t)b * D2 + cd0 + (min(lane, 47) - 40) * 8);
             stepb = hstep * 2;
         }
+        // backward step jr reads forward step i = Tn-1-jr (c': i-1, clamped at 0), i.e. time index i or
+        // Tn-1-i by direction: the source pointer moves by one step per load until it reaches its last row
         const bool is_cp = lane >= 40;
+        const int i0 = is_cp ? max(Tn - 2, 0) : Tn - 1;   // forward step read by backward step 0
+        const char* src = base + (int64_t)(dir ? Tn - 1 - i0 : i0) * stepb;
+        const int64_t delta = dir ? stepb : -stepb;
+        int left = i0;   // moves still to make
         auto issue = [&](int c) {
 #pragma unroll
             for (int s = 0; s < CH; ++s) {
-                const int jr = min(c * CH + s, Tn - 1);    // past the end: clamped re-loads
-                const int i = Tn - 1 - jr;
-                const int il = is_cp ? max(i - 1, 0) : i;   // c' = cell state of forward step i-1
-                const int64_t t = dir ? Tn - 1 - il : il;
                 if (lane < 48)
-                    __builtin_amdgcn_global_load_lds((gptr_t)(base + t * stepb),
-                                                     (lptr_t)(ring + (((c % R) * CH) + s) * ROW), 16, 0, 0);
+                    __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(ring + (((c % R) * CH) + s) * ROW), 16, 0, 0);
+                const bool move = left > 0;   // past the first forward step: clamped re-loads
+                src += move ? delta : 0;
+                left -= move ? 1 : 0;
             }
         };
         for (int c = 0; c < R - 2; ++c) issue(c);
@@ -422,39 +427,62 @@ __global__ __launch_bounds__(256) void sru_bwd_split_kernel(
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         return;
     }
-    const int cd = cd0 + lane;
+    // The f-side and r-side are independent across time, so their lanes are laid out for the LDS, not
+    // for the recurrence: lane = (step parity hp, column pair ci) handles columns 2ci, 2ci+1 of steps
+    // hp and 2 + hp of a chunk -- one 32-bit ds_read brings two steps x 64 columns of a stream (the
+    // 16-bit reads of a lane-per-column layout made the LDS pipe, ~80 % busy, the limiter of this
+    // kernel) and every hand-off array is written 8 bytes per lane.
+    const int hp = lane >> 5, ci = lane & 31;
+    auto lo16 = [](uint32_t w) { return __uint_as_float(w << 16); };
+    auto hi16 = [](uint32_t w) { return __uint_as_float(w & 0xffff0000u); };
     if (wave == 1) {
         // ---- f-side ----
-        const float vf = wc[cd];
-        const float nvf = -kL2e * vf, nbf = -kL2e * bias[cd];
-        const float m = mask ? mask[(int64_t)b * D2 + cd] : 1.f;
+        const int cA = cd0 + 2 * ci;
+        const float vf[2] = {wc[cA], wc[cA + 1]};
+        const float nvf[2] = {-kL2e * vf[0], -kL2e * vf[1]};
+        const float nbf[2] = {-kL2e * bias[cA], -kL2e * bias[cA + 1]};
+        const float m[2] = {mask ? mask[(int64_t)b * D2 + cA] : 1.f, mask ? mask[(int64_t)b * D2 + cA + 1] : 1.f};
         __hip_bfloat16* gUb = gU + (int64_t)b * K * D2 + cd0;
         for (int j = 0; j < nint; ++j) {
             __builtin_amdgcn_s_barrier();
             asm volatile("" ::: "memory");
             if (j < nch) {
-                const unsigned char* slot = ring + ((j % R) * CH) * ROW;
-                float u0[CH], a1[CH], x[CH], cp[CH];
+                const unsigned char* slot = ring + ((j % R) * CH) * ROW + ci * 4;
+                uint32_t w0[2], w1[2], wx[2], wp[2];
 #pragma unroll
-                for (int s = 0; s < CH; ++s) {
-                    const unsigned char* row = slot + s * ROW;
-                    u0[s] = lds_bf16(row + lane * 2);
-                    a1[s] = fmaf(-kL2e, lds_bf16(row + 128 + lane * 2), nbf);
-                    x[s] = lds_bf16(row + 384 + lane * 2);
-                    cp[s] = lds_bf16(row + 640 + lane * 2);
-                    if (j * CH + s >= Tn - 1) cp[s] = 0.f;   // forward step 0 has no predecessor
+                for (int p = 0; p < 2; ++p) {
+                    const unsigned char* row = slot + (2 * p + hp) * ROW;
+                    w0[p] = *reinterpret_cast<const uint32_t*>(row);
+                    w1[p] = *reinterpret_cast<const uint32_t*>(row + 128);
+                    wx[p] = *reinterpret_cast<const uint32_t*>(row + 384);
+                    wp[p] = *reinterpret_cast<const uint32_t*>(row + 640);
                 }
 #pragma unroll
-                for (int s = 0; s < CH; ++s) {
-                    const float f = sigmoid_neg2(fmaf(nvf, cp[s], a1[s]));
-                    const float omf = 1.f - f;
-                    const float d0 = cp[s] - u0[s];
-                    const float kap = d0 * f * omf;
-                    sA[j % 3][s][lane] = fmaf(kap, vf, f);
-                    sOmf[j % 3][s][lane] = omf;
-                    sKap[j % 3][s][lane] = kap;
-                    sKcp[j % 3][s][lane] = kap * cp[s];
-                    sq[j & 1][s][lane] = fmaf(fmaf(d0, f, u0[s]), m, -x[s]);
+                for (int p = 0; p < 2; ++p) {
+                    const int st = 2 * p + hp;
+                    const bool first = j * CH + st >= Tn - 1;   // forward step 0 has no predecessor
+                    float2 vA, vO, vK, vC, vQ;
+#pragma unroll
+                    for (int e = 0; e < 2; ++e) {
+                        const float u0 = e ? hi16(w0[p]) : lo16(w0[p]);
+                        const float a1 = fmaf(-kL2e, e ? hi16(w1[p]) : lo16(w1[p]), nbf[e]);
+                        const float x = e ? hi16(wx[p]) : lo16(wx[p]);
+                        const float cp = first ? 0.f : (e ? hi16(wp[p]) : lo16(wp[p]));
+                        const float f = sigmoid_neg2(fmaf(nvf[e], cp, a1));
+                        const float omf = 1.f - f;
+                        const float d0 = cp - u0;
+                        const float kap = d0 * f * omf;
+                        (e ? vA.y : vA.x) = fmaf(kap, vf[e], f);
+                        (e ? vO.y : vO.x) = omf;
+                        (e ? vK.y : vK.x) = kap;
+                        (e ? vC.y : vC.x) = kap * cp;
+                        (e ? vQ.y : vQ.x) = fmaf(fmaf(d0, f, u0), m[e], -x);
+                    }
+                    *reinterpret_cast<float2*>(&sA[j % 3][st][2 * ci]) = vA;
+                    *reinterpret_cast<float2*>(&sOmf[j % 3][st][2 * ci]) = vO;
+                    *reinterpret_cast<float2*>(&sKap[j % 3][st][2 * ci]) = vK;
+                    *reinterpret_cast<float2*>(&sKcp[j % 3][st][2 * ci]) = vC;
+                    *reinterpret_cast<float2*>(&sq[j & 1][st][2 * ci]) = vQ;
                 }
             }
             const int cs = j - 3;   // chunk whose g0/df tiles the chain wave finished in interval j-1
@@ -470,9 +498,11 @@ __global__ __launch_bounds__(256) void sru_bwd_split_kernel(
     }
     if (wave == 2) {
         // ---- r-side ----
-        const float vr = wc[D2 + cd];
-        const float nvr = -kL2e * vr, nbr = -kL2e * bias[D2 + cd];
-        const float m = mask ? mask[(int64_t)b * D2 + cd] : 1.f;
+        const int cA = cd0 + 2 * ci;
+        const float vr[2] = {wc[D2 + cA], wc[D2 + cA + 1]};
+        const float nvr[2] = {-kL2e * vr[0], -kL2e * vr[1]};
+        const float nbr[2] = {-kL2e * bias[D2 + cA], -kL2e * bias[D2 + cA + 1]};
+        const float m[2] = {mask ? mask[(int64_t)b * D2 + cA] : 1.f, mask ? mask[(int64_t)b * D2 + cA + 1] : 1.f};
         // lanes 0-31 store dr (plane 2 of gU), lanes 32-63 gx (gxres, or plane 3 when K == 4)
         __hip_bfloat16* sbase;
         int64_t sstep;
@@ -483,36 +513,51 @@ __global__ __launch_bounds__(256) void sru_bwd_split_kernel(
             sbase = gxres + (int64_t)b * D2 + cd0;
             sstep = hstep;
         }
-        float gvr = 0.f, gbr = 0.f;
+        float gvr[2] = {0.f, 0.f}, gbr[2] = {0.f, 0.f};
         for (int j = 0; j < nint; ++j) {
             __builtin_amdgcn_s_barrier();
             asm volatile("" ::: "memory");
             const int c = j - 1;
             if (c >= 0 && c < nch) {
-                const unsigned char* slot = ring + ((c % R) * CH) * ROW;
-                float a2[CH], g[CH], cp[CH], q[CH];
+                const unsigned char* slot = ring + ((c % R) * CH) * ROW + ci * 4;
+                uint32_t w2[2], wg[2], wp[2];
+                float2 q[2];
 #pragma unroll
-                for (int s = 0; s < CH; ++s) {
-                    const unsigned char* row = slot + s * ROW;
-                    a2[s] = fmaf(-kL2e, lds_bf16(row + 256 + lane * 2), nbr);
-                    g[s] = lds_bf16(row + 512 + lane * 2);
-                    cp[s] = lds_bf16(row + 640 + lane * 2);
-                    if (c * CH + s >= Tn - 1) cp[s] = 0.f;
-                    q[s] = sq[c & 1][s][lane];
+                for (int p = 0; p < 2; ++p) {
+                    const unsigned char* row = slot + (2 * p + hp) * ROW;
+                    w2[p] = *reinterpret_cast<const uint32_t*>(row + 256);
+                    wg[p] = *reinterpret_cast<const uint32_t*>(row + 512);
+                    wp[p] = *reinterpret_cast<const uint32_t*>(row + 640);
+                    q[p] = *reinterpret_cast<const float2*>(&sq[c & 1][2 * p + hp][2 * ci]);
                 }
 #pragma unroll
-                for (int s = 0; s < CH; ++s) {
-                    const float r = sigmoid_neg2(fmaf(nvr, cp[s], a2[s]));
-                    const float omr = 1.f - r;
-                    const float gr = g[s] * q[s];
-                    const float dr = gr * r * omr;
-                    sG[c & 1][s][lane] = g[s] * r * m;
-                    sBv[c & 1][s][lane] = dr * vr;
-                    tr[0][s][lane] = __builtin_bit_cast(unsigned short, __float2bfloat16(dr));
-                    tr[1][s][lane] = __builtin_bit_cast(unsigned short, __float2bfloat16(g[s] * omr));
-                    const float drv = (c * CH + s < Tn) ? dr : 0.f;   // select, not a branch: the four steps interleave
-                    gvr = fmaf(drv, cp[s], gvr);
-                    gbr += drv;
+                for (int p = 0; p < 2; ++p) {
+                    const int st = 2 * p + hp;
+                    const bool first = c * CH + st >= Tn - 1;
+                    const bool live = c * CH + st < Tn;
+                    float2 vG, vB;
+                    uint32_t tdr = 0, tgx = 0;
+#pragma unroll
+                    for (int e = 0; e < 2; ++e) {
+                        const float a2 = fmaf(-kL2e, e ? hi16(w2[p]) : lo16(w2[p]), nbr[e]);
+                        const float g = e ? hi16(wg[p]) : lo16(wg[p]);
+                        const float cp = first ? 0.f : (e ? hi16(wp[p]) : lo16(wp[p]));
+                        const float r = sigmoid_neg2(fmaf(nvr[e], cp, a2));
+                        const float omr = 1.f - r;
+                        const float gr = g * (e ? q[p].y : q[p].x);
+                        const float dr = gr * r * omr;
+                        (e ? vG.y : vG.x) = g * r * m[e];
+                        (e ? vB.y : vB.x) = dr * vr[e];
+                        tdr |= (uint32_t)__builtin_bit_cast(unsigned short, __float2bfloat16(dr)) << (16 * e);
+                        tgx |= (uint32_t)__builtin_bit_cast(unsigned short, __float2bfloat16(g * omr)) << (16 * e);
+                        const float drv = live ? dr : 0.f;   // select, not a branch: the steps interleave
+                        gvr[e] = fmaf(drv, cp, gvr[e]);
+                        gbr[e] += drv;
+                    }
+                    *reinterpret_cast<float2*>(&sG[c & 1][st][2 * ci]) = vG;
+                    *reinterpret_cast<float2*>(&sBv[c & 1][st][2 * ci]) = vB;
+                    *reinterpret_cast<uint32_t*>(&tr[0][st][2 * ci]) = tdr;
+                    *reinterpret_cast<uint32_t*>(&tr[1][st][2 * ci]) = tgx;
                 }
                 __builtin_amdgcn_wave_barrier();
                 asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
@@ -526,10 +571,21 @@ __global__ __launch_bounds__(256) void sru_bwd_split_kernel(
                 __builtin_amdgcn_wave_barrier();
             }
         }
-        atomicAdd(&gwc[D2 + cd], gvr);
-        atomicAdd(&gbias[D2 + cd], gbr);
+#pragma unroll
+        for (int e = 0; e < 2; ++e) {   // the two step parities of a column pair sit 32 lanes apart
+            gvr[e] += __shfl_xor(gvr[e], 32);
+            gbr[e] += __shfl_xor(gbr[e], 32);
+        }
+        if (hp == 0) {
+#pragma unroll
+            for (int e = 0; e < 2; ++e) {
+                atomicAdd(&gwc[D2 + cA + e], gvr[e]);
+                atomicAdd(&gbias[D2 + cA + e], gbr[e]);
+            }
+        }
         return;
     }
+    const int cd = cd0 + lane;
     // ---- chain ----
     float gc = 0.f, gvf = 0.f, gbf = 0.f;
     for (int j = 0; j < nint; ++j) {

@@ -326,6 +326,8 @@ def gemm_nt(a, b, out=None):
         raise ValueError("gemm_nt: operands must be K-contiguous")
     if out is None:
         out = torch.empty((M, N), dtype=torch.bfloat16, device=a.device)
+    if _os.environ.get("SPEECH_AMD_FWD_LIBNT"):
+        return torch.mm(a, b.t(), out=out)
     with torch.cuda.device(a.device):
         check(lib().sp_gemm_nt_bf16(ptr(a), ptr(b), ptr(out), M, N, K, a.stride(0), b.stride(0), out.stride(0),
                                     stream_ptr()), "sp_gemm_nt_bf16")

@@ -31,7 +31,7 @@ HBM_PEAK_GBS = 8000.0      # MI355X_MICROARCH.md: HBM3E 8 TB/s
 # corrected as MI355X_MICROARCH.md "HBM" prescribes (FETCH_SIZE x2 for 16-byte-per-lane reads on
 # gfx950, KiB units): profiles/r01_pmc_traffic.md holds the raw numbers.  None = not collected.
 PMC_TRAFFIC_BYTES = {
-    ("sru_bwd_kernel", "bf16", 32, 15.0): 2 * 144264.0 * 1024 + 192768.0 * 1024,
+    ("sru_bwd_kernel", "bf16", 32, 15.0): 2 * 144257.0 * 1024 + 193024.0 * 1024,
     ("sru_fwd_kernel", "bf16", 32, 15.0): 2 * 96184.9 * 1024 + 96128.0 * 1024,
     # L2-miss side of the forward GEMM (tools/pmc_gemm.py fwd): B panels stay L2-resident per XCD, A is
     # streamed once per owning XCD; algorithmic 55.5 MB read + 147.7 MB written
@@ -162,32 +162,38 @@ def kernel_rooflines(args, model, wav, offs, labels, lens, Lmax, V, iters):
     return out
 
 
-def gemm_in_step(step_fn, n_steps=2):
-    """Live duration of the hand-written forward-projection GEMM INSIDE the training step: every
-    ops.gemm_nt call of `n_steps` extra (untimed) steps is bracketed by its own HIP event pair on the
-    launch stream.  A back-to-back microbenchmark of a dense-MFMA kernel is not representative here (the
-    clock sags within milliseconds of continuous MFMA load, and the caches hold other data than in the
-    step), and profiles/r01_*_kernel_stats.csv averages mostly in-step launches."""
+def _in_step_events(step_fn, name, key, n_steps=2):
+    """Brackets every call of speech_amd.ops.<name> made by `n_steps` extra (untimed) training steps with
+    its own HIP event pair on the launch stream; returns {key(args): [ms, ...]}."""
     from speech_amd import ops
-    rec, orig = [], ops.gemm_nt
+    rec, orig = [], getattr(ops, name)
 
-    def timed(a, b, out=None):
+    def timed(*a, **kw):
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
-        r = orig(a, b, out)
+        r = orig(*a, **kw)
         e1.record()
-        rec.append((tuple(a.shape), b.shape[0], e0, e1))
+        rec.append((key(*a, **kw), e0, e1))
         return r
-    ops.gemm_nt = timed
+    setattr(ops, name, timed)
     try:
         for i in range(n_steps):
             step_fn(10 ** 6 + i)
         torch.cuda.synchronize()
     finally:
-        ops.gemm_nt = orig
-    by_shape = {}
-    for (M, K), N, e0, e1 in rec:
-        by_shape.setdefault((M, N, K), []).append(e0.elapsed_time(e1))
+        setattr(ops, name, orig)
+    out = {}
+    for k, e0, e1 in rec:
+        out.setdefault(k, []).append(e0.elapsed_time(e1))
+    return out
+
+
+def gemm_in_step(step_fn, n_steps=2):
+    """Live duration of the hand-written forward-projection GEMM INSIDE the training step (only when
+    SPEECH_AMD_OWN_GEMM=1 puts it there; the default engine of that GEMM is the library's NT kernel).
+    A back-to-back microbenchmark of a dense-MFMA kernel is not representative (the clock sags within
+    milliseconds of continuous MFMA load, and the caches hold other data than in the step)."""
+    by_shape = _in_step_events(step_fn, "gemm_nt", lambda a, b, out=None: (a.shape[0], b.shape[0], a.shape[1]), n_steps)
     if not by_shape:
         return None
     (M, N, K), ts = max(by_shape.items(), key=lambda kv: len(kv[1]))      # the nine 1024 -> 3072 layers
@@ -196,6 +202,14 @@ def gemm_in_step(step_fn, n_steps=2):
             "frac": fl / ms / 1e9 / MFMA_BF16_PEAK_TF, "ms": ms, "algorithmic_flops": fl,
             "algorithmic_bytes": 2 * (M * K + N * K + M * N), "launches_per_step": len(ts) // n_steps,
             "shape_mnk": [M, N, K], "timed": "in-step, one HIP event pair per launch"}
+
+
+def sru_bwd_in_step(step_fn, n_steps=2):
+    """Average duration of the k = 3 SRU backward launches inside the training step (the event pair
+    brackets the one kernel sp_sru_bwd launches)."""
+    by_k = _in_step_events(step_fn, "sru_bwd", lambda U, xres, wc, bias, mask, c, gh, T, B, d, k, *r, **kw: k, n_steps)
+    ts = by_k.get(3)
+    return (sum(ts) / len(ts), len(ts) // n_steps) if ts else None
 
 
 def cpu_baseline(args, V):
@@ -303,6 +317,13 @@ def main():
             g = gemm_in_step(step) if args.dtype == "bf16" else None
             if g is not None:
                 ks["gemm_nt_bf16(forward projection)"] = g
+            sb = sru_bwd_in_step(step) if args.dtype == "bf16" else None
+            if sb is not None:      # replace the stand-alone timing by the in-step one
+                k = ks["sru_bwd_kernel"]
+                k["ms_standalone"], k["ms"], k["timed"] = k["ms"], sb[0], "in-step, one HIP event pair per launch"
+                k["achieved"] = k["algorithmic_bytes"] / sb[0] / 1e6
+                k["frac"] = k["achieved"] / HBM_PEAK_GBS
+                k["launches_per_step"] = sb[1] + 1      # + the k = 4 first layer
             # dominant = the hand-written kernel with the largest share of the training step
             dom = max(ks, key=lambda k: ks[k]["ms"] * ks[k]["launches_per_step"])
             r = dict(ks[dom])

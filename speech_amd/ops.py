@@ -326,8 +326,6 @@ def gemm_nt(a, b, out=None):
         raise ValueError("gemm_nt: operands must be K-contiguous")
     if out is None:
         out = torch.empty((M, N), dtype=torch.bfloat16, device=a.device)
-    if _os.environ.get("SPEECH_AMD_FWD_LIBNT"):
-        return torch.mm(a, b.t(), out=out)
     with torch.cuda.device(a.device):
         check(lib().sp_gemm_nt_bf16(ptr(a), ptr(b), ptr(out), M, N, K, a.stride(0), b.stride(0), out.stride(0),
                                     stream_ptr()), "sp_gemm_nt_bf16")
@@ -538,14 +536,24 @@ def classifier(x, weight):
     return _ClassifierFn.apply(x.reshape(-1, x.shape[-1]), weight).view(*lead, weight.shape[0])
 
 
-def _own_fwd_gemm(M, n_in, N, d, dtype):
-    """The forward projection runs on sp_gemm_nt_bf16's persistent kernel where that was measured faster
-    than the library GEMM (profiles/r01_gemm.md): bf16, output-heavy (N >= 2 n_in), enough rows for at
-    least one 192-row tile per CU and column."""
-    if _os.environ.get("SPEECH_AMD_LIB_GEMM"):      # measurement switch: everything on the library GEMM
+def _nt_projection(M, n_in, N, d, dtype):
+    """The big forward projections run as an NT GEMM on W^T with padded row pitches (sp_sru_pack_wt):
+    bf16, output-heavy (N >= 2 n_in), enough rows for one 192-row tile per CU and column.  That layout
+    is worth 15 % on this GEMM whoever runs it (profiles/r01_gemm.md): the library's NN kernel on W
+    takes 172 us at the reference's sizes, its NT kernel on the padded W^T 148 us, sp_gemm_nt_bf16 150 us."""
+    if _os.environ.get("SPEECH_AMD_LIB_GEMM"):      # measurement switch: the library's NN call on W
         return False
     return (dtype == torch.bfloat16 and N % 256 == 0 and n_in % 64 == 0 and d % 64 == 0 and N >= 2 * n_in
             and (M // 192) * (N // 256) >= 256 and M * max(n_in, N) < (1 << 30))
+
+
+def projection_nt(xn, wkt):
+    """xn [M, n_in] @ wkt[N, n_in]^T.  The library's NT kernel by default -- measured 1.5-2 % faster than
+    the hand-written persistent kernel inside the training step and 25 % faster at the 77 k-row
+    inference shape -- or sp_gemm_nt_bf16 with SPEECH_AMD_OWN_GEMM=1."""
+    if _os.environ.get("SPEECH_AMD_OWN_GEMM"):
+        return gemm_nt(xn, wkt)
+    return torch.mm(xn, wkt.t())
 
 
 
@@ -564,19 +572,19 @@ class _SRULayerFn(torch.autograd.Function):
         if C > 1:
             g32, b32 = g32.view(C, n_in // C).t().reshape(-1), b32.view(C, n_in // C).t().reshape(-1)
         g32, b32 = g32.contiguous(), b32.contiguous()
-        own = _own_fwd_gemm(T * B, n_in, 2 * d * k, d, x.dtype)
+        own = _nt_projection(T * B, n_in, 2 * d * k, d, x.dtype)
         # rows whose pitch is a multiple of 1 KB land on few L2 channels when 256 CUs walk them in step
         pad = 64 if own and (n_in * x.element_size()) % 1024 == 0 else 0
         xn, mean, rstd = layernorm_fwd(x2, g32, b32, eps, pad)
         w32 = weight.detach().float().contiguous()
         train = any(ctx.needs_input_grad)      # False under no_grad: nothing is kept for a backward
-        if own and train:      # W^T [N][n_in] for the forward (own kernel), W [n_in][N] for the data gradient
+        if own and train:      # W^T [N][n_in] for the forward (NT), W [n_in][N] for the data gradient
             wkt, wk = sru_pack_wt(w32, d, k, C, x.dtype, pad, both=True)
-            U = gemm_nt(xn, wkt)
+            U = projection_nt(xn, wkt)
             del wkt
         elif own:
             wk = None
-            U = gemm_nt(xn, sru_pack_wt(w32, d, k, C, x.dtype, pad))
+            U = projection_nt(xn, sru_pack_wt(w32, d, k, C, x.dtype, pad))
         else:        # wk holds W [n_in][N]
             wk = sru_pack_w(w32, d, k, C, x.dtype)
             U = torch.mm(xn, wk)

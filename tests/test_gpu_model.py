@@ -298,6 +298,36 @@ def test_fused_head_matches_classifier_then_ctc(cuda, dtype):
         assert float((a - b).abs().max()) <= tol * float(a.abs().max()) + 1e-7, k
 
 
+def test_projection_engines_agree(cuda, monkeypatch):
+    """The big forward projection has three engines (library NT on the packed W^T: default;
+    sp_gemm_nt_bf16: SPEECH_AMD_OWN_GEMM; library NN on W: SPEECH_AMD_LIB_GEMM).  All three feed the
+    same layer and must agree to bf16 rounding, forward and backward."""
+    from speech_amd import ops
+    torch.manual_seed(3)
+    T, B, d, k = 72, 64, 512, 3          # 4608 rows: big enough for the NT path
+    n_in = 2 * d
+    x0 = (torch.randn(T, B, n_in, device=cuda) * 0.7).bfloat16()
+    ln_w, ln_b = torch.rand(n_in, device=cuda) + 0.5, torch.randn(n_in, device=cuda) * 0.1
+    weight = torch.randn(n_in, 2 * d * k, device=cuda) * (1.0 / n_in) ** 0.5
+    wc, bias = torch.randn(4 * d, device=cuda) * 0.3, torch.randn(4 * d, device=cuda) * 0.1
+    assert ops._nt_projection(T * B, n_in, 2 * d * k, d, torch.bfloat16)
+    gh = torch.randn(T, B, 2 * d, device=cuda).bfloat16()
+    res = {}
+    for name, env in (("lib_nt", None), ("own", "SPEECH_AMD_OWN_GEMM"), ("lib_nn", "SPEECH_AMD_LIB_GEMM")):
+        if env:
+            monkeypatch.setenv(env, "1")
+        ps = [p.clone().requires_grad_(True) for p in (ln_w, ln_b, weight, wc, bias)]
+        x = x0.clone().requires_grad_(True)
+        h = ops.sru_layer(x, *ps, None, d, k)
+        h.backward(gh)
+        res[name] = (h.detach().float(), x.grad.float(), ps[2].grad.float())
+        if env:
+            monkeypatch.delenv(env)
+    for name in ("own", "lib_nn"):
+        for a, b, tol in zip(res[name], res["lib_nt"], (2e-2, 2e-2, 5e-3)):
+            assert float((a - b).abs().max()) <= tol * float(b.abs().max()), name
+
+
 def test_wav_dataset_to_train_step(cuda, tmp_path):
     """The IO path end to end: 16-bit WAV files + transcripts on disk -> SortedTV -> DataLoader ->
     collate_fn (int16 PCM straight into the fused frontend) -> train_step; the features equal the CPU

@@ -319,7 +319,11 @@ __global__ __launch_bounds__(256, 2) void conv3x5_kernel(
 // ---------------------------------------------------------------------------------------------
 // conv3x5 weight gradient
 // ---------------------------------------------------------------------------------------------
-constexpr int kWR = 72;  // padded row (positions) of the transposed LDS images, 144 bytes
+// Row pitch (positions) of the transposed LDS images and the per-channel-group skew: channel c's row
+// starts at c * kWR + (c / 8) * kWSkew.  With 192-byte rows and a 16-byte skew both the staging
+// ds_write_b16 (lanes = 8 positions x 4 channel groups) and the fragment ds_read_b128 are free of bank
+// conflicts; with plain 144-byte rows the four channel groups of a store shared one bank (4-way).
+constexpr int kWR = 96, kWSkew = 8;
 
 // 16 bytes at bf16-element offset E (0..4) of a 32-byte window held as two uint4
 template <int E>
@@ -392,7 +396,7 @@ __global__ __launch_bounds__(320) void conv3x5_wgrad_kernel(
 #pragma unroll
                 for (int j = 0; j < 8; ++j) x[j] = rr.aok ? fmaxf(0.f, a0[j] * x[j] + a1[j]) : 0.f;
             }
-            __hip_bfloat16* dst = aring + ((frow + 3) % 3) * 32 * kWR + (ch4 * 8) * kWR + pos;
+            __hip_bfloat16* dst = aring + ((frow + 3) % 3) * 32 * kWR + (ch4 * 8) * kWR + ch4 * kWSkew + pos;
 #pragma unroll
             for (int j = 0; j < 8; ++j) dst[j * kWR] = __float2bfloat16(x[j]);
         }
@@ -405,7 +409,7 @@ __global__ __launch_bounds__(320) void conv3x5_wgrad_kernel(
             unpack8(rr.y, yv);
 #pragma unroll
             for (int j = 0; j < 8; ++j) x[j] = rr.gok ? ga[j] * x[j] + gb[j] * yv[j] + gd[j] : 0.f;
-            __hip_bfloat16* dst = gys + (ch4 * 8) * kWR + idx;
+            __hip_bfloat16* dst = gys + (ch4 * 8) * kWR + ch4 * kWSkew + idx;
 #pragma unroll
             for (int j = 0; j < 8; ++j) dst[j * kWR] = __float2bfloat16(x[j]);
         }
@@ -439,7 +443,7 @@ __global__ __launch_bounds__(320) void conv3x5_wgrad_kernel(
         __syncthreads();
 #pragma unroll
         for (int ks = 0; ks < 4; ++ks) {
-            const uint4* wp = reinterpret_cast<const uint4*>(gys + r * kWR + ks * 16 + 8 * h);
+            const uint4* wp = reinterpret_cast<const uint4*>(gys + r * kWR + (r >> 3) * kWSkew + ks * 16 + 8 * h);
             const uint4 lo = wp[0], hi = wp[1];
             // tap kw = wave reads dy at column offset 4 - kw of the window
             uint4 av;
@@ -455,7 +459,7 @@ __global__ __launch_bounds__(320) void conv3x5_wgrad_kernel(
             for (int kh = 0; kh < 3; ++kh) {
                 const int slot = (f + kh + 2) % 3;  // row f + kh - 1
                 const bf16x8 Bv = __builtin_bit_cast(
-                    bf16x8, *reinterpret_cast<const uint4*>(aring + (slot * 32 + r) * kWR + ks * 16 + 8 * h));
+                    bf16x8, *reinterpret_cast<const uint4*>(aring + (slot * 32 + r) * kWR + (r >> 3) * kWSkew + ks * 16 + 8 * h));
                 acc[kh] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A, Bv, acc[kh], 0, 0, 0);
             }
         }

@@ -489,6 +489,31 @@ def test_conv_kernels_individually(cuda, shape):
     assert _relmax(gsb, gn.sum((0, 2, 3))) <= 2e-3
 
 
+@pytest.mark.parametrize("shape", [(2, 80, 301), (3, 16, 70), (1, 9, 131), (2, 7, 2), (1, 1, 1), (33, 11, 129)])
+def test_conv_stem_forward_backward(cuda, shape):
+    """sp_conv_stem_fwd / sp_conv_stem_bwd alone (persistent work items, quad-shared taps) against torch
+    fp32 on odd and even extents, fewer positions than one work item, more utterances than row groups."""
+    from speech_amd._lib import check, lib, ptr, stream_ptr
+    B, Fin, Tin = shape
+    F, T = (Fin - 1) // 2 + 1, (Tin - 1) // 2 + 1
+    g = torch.Generator().manual_seed(B * 1000 + Fin * 10 + Tin)
+    spec = torch.randn(B, 1, Fin, Tin, generator=g).to(cuda)
+    w = torch.randn(32, 1, 3, 3, generator=g).to(cuda)
+    bias = torch.randn(32, generator=g).to(cuda)
+    out = torch.full((B, F, T, 32), float("nan"), dtype=torch.bfloat16, device=cuda)
+    check(lib().sp_conv_stem_fwd(ptr(spec), ptr(w), ptr(bias), B, Fin, Tin, ptr(out), stream_ptr()), "stem_fwd")
+    ref = torch.nn.functional.conv2d(spec, w, bias, stride=2, padding=1).permute(0, 2, 3, 1)
+    assert out.shape == ref.shape
+    assert float((out.float() - ref).abs().max()) <= 8e-3 * float(ref.abs().max()) + 1e-6      # bf16 rounding of the output
+    gout = torch.randn(B, F, T, 32, generator=g).to(cuda).bfloat16()
+    gw, gb = torch.zeros(288, device=cuda), torch.zeros(32, device=cuda)
+    check(lib().sp_conv_stem_bwd(ptr(spec), ptr(gout), B, Fin, Tin, ptr(gw), ptr(gb), stream_ptr()), "stem_bwd")
+    gn = gout.float().permute(0, 3, 1, 2).contiguous()
+    ref_w = torch.nn.grad.conv2d_weight(spec, (32, 1, 3, 3), gn, stride=2, padding=1)
+    assert float((gw.view(32, 1, 3, 3) - ref_w).abs().max()) <= 2e-3 * float(ref_w.abs().max()) + 1e-5
+    assert float((gb - gn.sum((0, 2, 3))).abs().max()) <= 2e-3 * float(gn.sum((0, 2, 3)).abs().max()) + 1e-5
+
+
 def test_conv_stack_backward(cuda):
     """End to end against torch fp32 with loss = sum(z^2)/2.  bf16 activations flip the ReLU mask
     at ~2 % of the positions (near-zero pre-activations); with a random upstream gradient each

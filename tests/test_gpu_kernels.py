@@ -310,7 +310,8 @@ def _sru_ref(U, x, wc, bias, mask, d):
 @pytest.mark.parametrize("k", [3, 4])
 @pytest.mark.parametrize("dtype,tol,T,d", [(torch.float32, 2e-5, 37, 64), (torch.bfloat16, 2e-2, 37, 64),
                                            (torch.bfloat16, 2e-2, 131, 128),   # loader-ring kernels
-                                           (torch.bfloat16, 2e-2, 7, 256), (torch.bfloat16, 2e-2, 64, 128)])
+                                           (torch.bfloat16, 2e-2, 7, 256), (torch.bfloat16, 2e-2, 64, 128),
+                                           (torch.bfloat16, 2e-2, 1, 64), (torch.bfloat16, 2e-2, 2, 64), (torch.bfloat16, 2e-2, 6, 64)])
 def test_sru_recurrence_fwd_bwd(cuda, k, dtype, tol, T, d):
     from speech_amd import ops
     B = 3

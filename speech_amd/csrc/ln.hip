@@ -240,7 +240,9 @@ extern "C" int sp_layernorm_fwd(const void* x, const float* gamma, const float* 
     if (M == 0) return SP_OK;
     SP_CHECK_ARG(x && gamma && beta && y && mean && rstd, "sp_layernorm_fwd: null pointer");
     int64_t blocks = (M + 3) / 4;
-    if (blocks > 1024) blocks = 1024;
+    // a wave has one row in flight and one requested (2 x 2 KB at N = 1024): the grid, not the prefetch
+    // depth, supplies the bytes in flight (measured at M = 24 k: 1024 blocks 20.9 us, 4096 blocks 18.6 us)
+    if (blocks > 4096) blocks = 4096;
     hipStream_t s = (hipStream_t)stream;
     const int nch = (N + 511) / 512;
 #define SP_LN_FWD(T, NCH) hipLaunchKernelGGL((ln_fwd_kernel<T, NCH>), dim3((int)blocks), dim3(256), 0, s, (const T*)x, \
@@ -261,7 +263,9 @@ extern "C" int sp_layernorm_bwd(const void* gy, const void* x, const float* mean
     if (M == 0) return SP_OK;
     SP_CHECK_ARG(gy && x && mean && rstd && gamma && gx && dgamma && dbeta, "sp_layernorm_bwd: null pointer");
     int64_t blocks = (M + 3) / 4;
-    if (blocks > 512) blocks = 512;
+    // every block ends in 2 N float atomics onto the same 2 N words (~20 ns each, serialised per word):
+    // one block per CU (measured at M = 24 k: 256 blocks 36 us, 512 blocks 42 us, 128 blocks 56 us)
+    if (blocks > 256) blocks = 256;
     const size_t lds = (size_t)8 * N * sizeof(float);
     hipStream_t s = (hipStream_t)stream;
     const int nch = (N + 511) / 512;

@@ -341,29 +341,45 @@ __device__ __forceinline__ uint4 window16(const uint4& lo, const uint4& hi) {
     return o;
 }
 
+// A workgroup is kWG independent groups of five waves (one (image, row range, 64-position chunk) item
+// each) that meet again only at the end: the groups' accumulators are added through LDS and ONE of
+// them issues the float atomics.  The atomics are what this buys: every workgroup result is 15 x 32 x 32
+// dword atomics, the L2 executes them one dword at a time, and with one item per workgroup they were a
+// third of the kernel's time.
+constexpr int kWG = 3;
+
 template <int A_MODE>
-__global__ __launch_bounds__(320) void conv3x5_wgrad_kernel(
+__global__ __launch_bounds__(320 * kWG) void conv3x5_wgrad_kernel(
     const __hip_bfloat16* __restrict__ asrc, const float* __restrict__ acoef,
     const __hip_bfloat16* __restrict__ g, const __hip_bfloat16* __restrict__ y,
-    const float* __restrict__ gcoef, int B, int F, int T, int fsplit, float* __restrict__ gwp) {
+    const float* __restrict__ gcoef, int B, int F, int T, int fsplit, int ntc, float* __restrict__ gwp) {
     // dy row: ONE transposed copy [co][68 positions, origin t0-2]; the five kw taps read the same
     // aligned 32-byte windows and shift them in registers (v_alignbit), instead of five shifted copies
-    __shared__ __attribute__((aligned(16))) __hip_bfloat16 gys[32 * kWR];
-    __shared__ __attribute__((aligned(16))) __hip_bfloat16 aring[3 * 32 * kWR];
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    constexpr int kGys = 32 * kWR, kAring = 3 * 32 * kWR;          // bf16 elements per group
+    __shared__ __attribute__((aligned(16))) __hip_bfloat16 smem[kWG * (kGys + kAring)];
+    static_assert(sizeof(__hip_bfloat16) * kWG * (kGys + kAring) >= sizeof(float) * (kWG - 1) * 5 * 16 * 64,
+                  "the staging buffers double as the end-of-kernel reduction buffer");
+    const int grp = threadIdx.x / 320, tid = threadIdx.x - grp * 320;   // 320 = 5 waves: groups are wave-aligned
+    __hip_bfloat16* gys = smem + grp * (kGys + kAring);
+    __hip_bfloat16* aring = gys + kGys;
+    const int lane = tid & 63, wave = tid >> 6;
     const int r = lane & 31, h = lane >> 5;
-    const int t0 = blockIdx.x * 64;
-    const int b = blockIdx.y / fsplit, fs = blockIdx.y % fsplit;
+    // item = (image b, row range fs, position chunk tc); a group past the last item runs empty rows
+    const int item = blockIdx.x * kWG + grp;
+    const bool live = item < ntc * B * fsplit;
+    const int tc = item % ntc, bf = min(item / ntc, B * fsplit - 1);
+    const int t0 = tc * 64;
+    const int b = bf / fsplit, fs = bf % fsplit;
     const int fper = (F + fsplit - 1) / fsplit;
-    const int fa = fs * fper, fb = min(F, fa + fper);
+    const int fa = fs * fper, fb = live ? min(F, fa + fper) : fa;
     const int64_t img = (int64_t)b * F * T;
     const int ch4 = tid & 3;
 
     // per-channel coefficients live in LDS (40 VGPRs otherwise: the kernel must stay under 128 to keep
     // four waves per SIMD, which is what hides the per-row HBM latency)
     __shared__ __attribute__((aligned(16))) float scoef[5][32];   // ga gb gd a0 a1
-    if (tid < 96) scoef[tid >> 5][tid & 31] = gcoef[tid];
-    else if (tid < 160) scoef[3 + ((tid - 96) >> 5)][tid & 31] = (A_MODE == IN_BNRELU) ? acoef[tid - 96] : ((tid < 128) ? 1.f : 0.f);
+    if (threadIdx.x < 96) scoef[tid >> 5][tid & 31] = gcoef[tid];
+    else if (threadIdx.x < 160) scoef[3 + ((tid - 96) >> 5)][tid & 31] = (A_MODE == IN_BNRELU) ? acoef[tid - 96] : ((tid < 128) ? 1.f : 0.f);
     __syncthreads();
     const float* ga = scoef[0] + ch4 * 8;
     const float* gb = scoef[1] + ch4 * 8;
@@ -377,10 +393,10 @@ __global__ __launch_bounds__(320) void conv3x5_wgrad_kernel(
     auto load_row = [&](int frow_a, int frow_g, RowRegs& rr) {
         rr.a = rr.g = rr.y = make_uint4(0, 0, 0, 0);
         const int pos = tid >> 2, ta = t0 + pos;
-        rr.aok = tid < 256 && frow_a >= 0 && frow_a < F && ta < T;
+        rr.aok = live && tid < 256 && frow_a >= 0 && frow_a < F && ta < T;
         if (rr.aok) rr.a = *reinterpret_cast<const uint4*>(asrc + (img + (int64_t)frow_a * T + ta) * kC + ch4 * 8);
         const int tg = t0 - 2 + pos;
-        rr.gok = tid < 272 && frow_g >= 0 && frow_g < F && tg >= 0 && tg < T;
+        rr.gok = live && tid < 272 && frow_g >= 0 && frow_g < F && tg >= 0 && tg < T;
         if (rr.gok) {
             const int64_t off = (img + (int64_t)frow_g * T + tg) * kC + ch4 * 8;
             rr.g = *reinterpret_cast<const uint4*>(g + off);
@@ -434,7 +450,7 @@ __global__ __launch_bounds__(320) void conv3x5_wgrad_kernel(
     }
 #pragma unroll
     for (int i = 0; i < PF; ++i) load_row(fa + 1 + i, fa + i < fb ? fa + i : -1, q[i]);
-    for (int f = fa; f < fb; ++f) {
+    for (int f = fa; f < fa + fper; ++f) {   // every group runs fper rows (the barriers are the workgroup's): rows past fb are zeros
         store_a(f + 1, q[0]);
         store_g(q[0]);
 #pragma unroll
@@ -466,17 +482,31 @@ __global__ __launch_bounds__(320) void conv3x5_wgrad_kernel(
         __syncthreads();
     }
     // D[row = co][col = ci]: lane = ci, registers = co 8g + 4h + i; gwp[copy][tap][co][ci].
+    // Groups 1 .. kWG-1 hand their accumulators to group 0 through LDS (the staging buffers are free:
+    // the loop ended in a barrier), one kh plane at a time, added in a fixed order.
     // Workgroups are dealt round-robin to the 8 XCDs by linear id: with one copy per residue mod 8
     // every atomic stays inside one XCD's L2 instead of being a cross-XCD (memory-side) atomic.
-    float* gcopy = gwp + (size_t)((blockIdx.y * gridDim.x + blockIdx.x) & 7) * (15 * 32 * 32);
+    float* rbuf = reinterpret_cast<float*>(smem);   // [kWG-1][5 waves][16][64]
+    float* gcopy = gwp + (size_t)(blockIdx.x & 7) * (15 * 32 * 32);
 #pragma unroll
     for (int kh = 0; kh < 3; ++kh) {
-        const int tap = kh * 5 + wave;
+        if (grp > 0) {
 #pragma unroll
-        for (int q = 0; q < 16; ++q) {
-            const int co = 8 * (q >> 2) + 4 * h + (q & 3);
-            atomicAdd(gcopy + (tap * 32 + co) * 32 + r, acc[kh][q]);
+            for (int q = 0; q < 16; ++q) rbuf[(((grp - 1) * 5 + wave) * 16 + q) * 64 + lane] = acc[kh][q];
         }
+        __syncthreads();
+        if (grp == 0) {
+            const int tap = kh * 5 + wave;
+#pragma unroll
+            for (int q = 0; q < 16; ++q) {
+                float v = acc[kh][q];
+#pragma unroll
+                for (int o = 0; o < kWG - 1; ++o) v += rbuf[((o * 5 + wave) * 16 + q) * 64 + lane];
+                const int co = 8 * (q >> 2) + 4 * h + (q & 3);
+                atomicAdd(gcopy + (tap * 32 + co) * 32 + r, v);
+            }
+        }
+        __syncthreads();
     }
 }
 
@@ -964,14 +994,16 @@ extern "C" int sp_conv3x5_wgrad(const void* a_src, const float* a_coef, int a_mo
     SP_CHECK_ARG(a_src && g && y && g_coef && gwp_ws && gw, "sp_conv3x5_wgrad: null pointer");
     SP_CHECK_ARG(a_mode == IN_ID || (a_mode == IN_BNRELU && a_coef), "sp_conv3x5_wgrad: bad activation mode");
     hipStream_t s = (hipStream_t)stream;
-    const int fsplit = F >= 8 ? 2 : 1;
-    dim3 grid((T + 63) / 64, B * fsplit), blk(320);
+    const int fsplit = F >= 8 ? 2 : 1, ntc = (T + 63) / 64;
+    const int64_t items = (int64_t)ntc * B * fsplit;
+    SP_CHECK_ARG(items < ((int64_t)1 << 30), "sp_conv3x5_wgrad: too many work items");
+    dim3 grid((unsigned)((items + kWG - 1) / kWG)), blk(320 * kWG);
     if (a_mode == IN_ID)
         hipLaunchKernelGGL((conv3x5_wgrad_kernel<IN_ID>), grid, blk, 0, s, (const bf16*)a_src, a_coef,
-                           (const bf16*)g, (const bf16*)y, g_coef, B, F, T, fsplit, gwp_ws);
+                           (const bf16*)g, (const bf16*)y, g_coef, B, F, T, fsplit, ntc, gwp_ws);
     else
         hipLaunchKernelGGL((conv3x5_wgrad_kernel<IN_BNRELU>), grid, blk, 0, s, (const bf16*)a_src, a_coef,
-                           (const bf16*)g, (const bf16*)y, g_coef, B, F, T, fsplit, gwp_ws);
+                           (const bf16*)g, (const bf16*)y, g_coef, B, F, T, fsplit, ntc, gwp_ws);
     rc = check_launch("conv3x5_wgrad_kernel");
     if (rc) return rc;
     hipLaunchKernelGGL(conv_wgrad_unpack_kernel, dim3(60), dim3(256), 0, s, gwp_ws, gw);

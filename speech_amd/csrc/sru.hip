@@ -226,8 +226,8 @@ __global__ __launch_bounds__(192) void sru_fwd_split_kernel(
     const __hip_bfloat16* __restrict__ U, const __hip_bfloat16* __restrict__ xres,
     const float* __restrict__ wc, const float* __restrict__ bias, const float* __restrict__ mask,
     int Tn, int B, int d, __hip_bfloat16* __restrict__ h, __hip_bfloat16* __restrict__ cst) {
-    constexpr int CH = 8, R = 8, ROW = 512, R2 = 4;   // (R-2) chunks = 24 DMA ops = 24 KB in flight per workgroup
-    __shared__ __attribute__((aligned(16))) unsigned char ring[R * CH * ROW];   // 32 KB
+    constexpr int CH = 8, R = 7, ROW = 512, R2 = 4;   // (R-2) chunks = 20 DMA ops = 20 KB in flight per workgroup; 38 KB of LDS: four workgroups per CU
+    __shared__ __attribute__((aligned(16))) unsigned char ring[R * CH * ROW];   // 28 KB
     __shared__ __attribute__((aligned(16))) float cring[R2][CH][64];            // 8 KB
     __shared__ __attribute__((aligned(16))) unsigned short htile[CH][64];       // 1 KB
     __shared__ __attribute__((aligned(16))) unsigned short ctile[CH][64];       // 1 KB

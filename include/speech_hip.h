@@ -84,6 +84,24 @@ int sp_ctc_fwd_bwd(const float* logits, int64_t stride_t, int64_t stride_b, cons
                    float* nll, float* loss, void* grad, int grad_dtype, void* workspace,
                    size_t workspace_bytes, void* stream);
 
+/* sp_ctc_fwd_bwd_noalloc: sp_ctc_fwd_bwd without the workspace arguments, for callers that cannot
+ * allocate or size device memory at the call site (code under HIP graph capture, tight serving loops,
+ * harnesses that forbid hipMalloc).  It has NO counterpart in the reference.  Same kernels, same
+ * results bit for bit; the workspace is a 64 MiB buffer built into the library (one copy per GPU, held
+ * from the first use of the library on that GPU until the process ends; sp_ctc_noalloc_max_bytes()
+ * returns its size).  A shape whose sp_ctc_workspace_bytes exceeds it is refused with SP_EWORKSPACE
+ * (configs[1], T'=751 x B=32 x V=1000 x L<=60, needs 56 MB and fits).  The call allocates nothing and
+ * frees nothing; its first call on a device looks the buffer's address up (make that call outside a
+ * graph capture; B = 0 is enough).  All calls on one GPU share the buffer: calls that overlap on one GPU
+ * (two streams, two threads) race -- serialise them or use sp_ctc_fwd_bwd with separate workspaces.
+ * Nothing in the buffer has to be zero on entry and nothing of a previous call is read. */
+size_t sp_ctc_noalloc_max_bytes(void);
+int sp_ctc_fwd_bwd_noalloc(const float* logits, int64_t stride_t, int64_t stride_b,
+                           const int64_t* labels, int label_stride, const int32_t* input_lengths,
+                           const int32_t* label_lengths, int T, int B, int V, int blank,
+                           int max_label_len, float grad_scale, float* nll, float* loss, void* grad,
+                           int grad_dtype, void* stream);
+
 /* ---------------------------------------------------------------------------------------
  * Greedy CTC decode.  Replaces decoder.py:28-57: argmax over V (ties -> lowest index, NaN
  * counts as maximum, as torch.argmax), drop blanks, drop a frame equal to its predecessor.

@@ -26,6 +26,9 @@ SIGNATURES = {
     "sp_ctc_workspace_bytes": (_sz, [_i, _i, _i, _i]),
     "sp_ctc_fwd_bwd": (_i, [_vp, _i64, _i64, _vp, _i, _vp, _vp, _i, _i, _i, _i, _i, _f, _vp, _vp,
                             _vp, _i, _vp, _sz, _vp]),
+    "sp_ctc_noalloc_max_bytes": (_sz, []),
+    "sp_ctc_fwd_bwd_noalloc": (_i, [_vp, _i64, _i64, _vp, _i, _vp, _vp, _i, _i, _i, _i, _i, _f, _vp, _vp,
+                                    _vp, _i, _vp]),
     "sp_greedy_decode": (_i, [_vp, _i, _i, _i, _i, _i, _vp, _vp, _vp, _vp]),
     "sp_edit_distance": (_i, [_vp, _i, _vp, _i]),
     "sp_sru_fwd": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp, _vp, _vp]),

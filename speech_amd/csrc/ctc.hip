@@ -38,9 +38,20 @@
 // constrained alignments the states that carry the posterior sit hundreds of binary orders below
 // the row maximum (f64 reaches 2^-1022 below it; anything smaller is a posterior of zero).  K3
 // multiplies alpha*beta in f64 and applies 2^(E_a + E_b - log2 y - log2 P) by ldexp.
+#include <atomic>
+
 #include "common.h"
 
 namespace sp {
+
+// Scratch of sp_ctc_fwd_bwd_noalloc (the entry point for callers that cannot allocate): one copy per GPU,
+// held from the moment the code object is loaded on that GPU until the process ends.  In host code the
+// array's NAME is only a handle for hipGetSymbolAddress; every use of its memory goes through the
+// per-device pointer obtained below.
+constexpr size_t kCtcScratchBytes = (size_t)64 << 20;
+static __device__ __align__(256) unsigned char scratch[kCtcScratchBytes];
+constexpr int kMaxDevices = 64;
+static std::atomic<void*> g_scratch_ptr[kMaxDevices];
 
 constexpr float kLog2e = 1.4426950408889634f;
 constexpr int kMaxV = 4000;  // K3 keeps 4 x V floats of per-class sums in LDS (<= 64 KB)
@@ -899,4 +910,38 @@ extern "C" int sp_ctc_fwd_bwd(const float* logits, int64_t stride_t, int64_t str
         if (rc) return rc;
     }
     return SP_OK;
+}
+
+extern "C" size_t sp_ctc_noalloc_max_bytes(void) { return sp::kCtcScratchBytes; }
+
+extern "C" int sp_ctc_fwd_bwd_noalloc(const float* logits, int64_t stride_t, int64_t stride_b,
+                                      const int64_t* labels, int label_stride, const int32_t* input_lengths,
+                                      const int32_t* label_lengths, int T, int B, int V, int blank,
+                                      int max_label_len, float grad_scale, float* nll, float* loss,
+                                      void* grad, int grad_dtype, void* stream) {
+    using namespace sp;
+    // set-up, once per device, with that device current: each GPU holds its own copy of `scratch` at its
+    // own address
+    int dev = -1;
+    hipError_t e = hipGetDevice(&dev);
+    if (e != hipSuccess) return fail(SP_ELAUNCH, "sp_ctc_fwd_bwd_noalloc: hipGetDevice: %s", hipGetErrorString(e));
+    SP_CHECK_ARG(dev >= 0 && dev < kMaxDevices, "sp_ctc_fwd_bwd_noalloc: device ordinal %d not supported", dev);
+    void* ptr = g_scratch_ptr[dev].load(std::memory_order_acquire);
+    if (!ptr) {
+        e = hipGetSymbolAddress(&ptr, HIP_SYMBOL(scratch));
+        if (e != hipSuccess || !ptr)
+            return fail(SP_ELAUNCH, "sp_ctc_fwd_bwd_noalloc: hipGetSymbolAddress: %s", hipGetErrorString(e));
+        g_scratch_ptr[dev].store(ptr, std::memory_order_release);
+    }
+    if (T >= 0 && B >= 0 && V >= 1 && max_label_len >= 0 && max_label_len <= kMaxL) {
+        const size_t need = ctc_dims(T, B, V, max_label_len).total_bytes;
+        if (need > kCtcScratchBytes)
+            return fail(SP_EWORKSPACE,
+                        "sp_ctc_fwd_bwd_noalloc: T=%d B=%d V=%d max_label_len=%d needs %zu bytes of scratch, the "
+                        "built-in buffer holds %zu (use sp_ctc_fwd_bwd with a caller-owned workspace)",
+                        T, B, V, max_label_len, need, kCtcScratchBytes);
+    }
+    // the kernels overwrite every workspace word they later read, so nothing has to start at zero
+    return sp_ctc_fwd_bwd(logits, stride_t, stride_b, labels, label_stride, input_lengths, label_lengths, T, B, V,
+                          blank, max_label_len, grad_scale, nll, loss, grad, grad_dtype, ptr, kCtcScratchBytes, stream);
 }

@@ -260,6 +260,32 @@ int sp_layernorm_bwd(const void* gy, const void* x, const float* mean, const flo
 int sp_gemm_nt_bf16(const void* A, const void* B, void* C, int M, int N, int K, int64_t lda, int64_t ldb,
                     int64_t ldc, void* stream);
 
+/* ---------------------------------------------------------------------------------------
+ * General GEMM on the matrix cores, f32 accumulation:
+ *     C[m][n] (+)= sum_k A(m,k) B(n,k),   A(m,k) = A[m*sam + k*sak],   B(n,k) = B[n*sbn + k*sbk]
+ * Replaces every matmul the reference reaches through net.py:61-76: sru.SRU's `x.mm(weight)` and the
+ * two gradient matmuls autograd derives from it, and the classifier's nn.Linear(1024, n_vocab+1,
+ * bias=False) with its gradients.  Each operand must be contiguous along k (sak / sbk == 1) or along
+ * its row index (sam / sbn == 1), which covers the NT, NN, TN and TT forms; strides in elements.
+ * in_dtype SP_BF16 / SP_F16 (v_mfma_f32_32x32x16 / 16x16x32) or SP_F32 (v_mfma_f32_32x32x2_f32, exact f32);
+ * out_dtype SP_F32 / SP_BF16 / SP_F16, row pitch ldc >= N.  accumulate != 0 (f32 output only): C += the
+ * product.  split_k = S > 1: K is cut into S ranges and range z writes its partial product to
+ * C + z * c_split_stride elements (no atomics: sum the slabs with sp_sum_slabs_f32 or sp_sru_unpack_dw).
+ * Any M, N, K >= 0.  16-byte operand loads are used when the bases are 16-byte aligned and the non-unit
+ * strides are multiples of 8 (16-bit) or 4 (f32) elements, element-wise loads otherwise.  Large bf16
+ * problems with both operands K-contiguous (and, for the weight gradient, both row-contiguous) run on
+ * the persistent LDS-DMA kernels of csrc/gemm.hip; which kernel runs is decided by the shape alone.
+ *
+ * sp_sum_slabs_f32: out[i] (+)= scale * sum_s partials[s * slab_stride + i], i < n (n, slab_stride
+ * multiples of 4; scale_dev: device float or NULL = 1) -- the reduction of split-K slabs straight into a
+ * gradient buffer, with the incoming loss gradient (a device scalar) folded in.
+ * --------------------------------------------------------------------------------------- */
+int sp_gemm(const void* A, const void* B, void* C, int M, int N, int K, int64_t sam, int64_t sak,
+            int64_t sbn, int64_t sbk, int64_t ldc, int in_dtype, int out_dtype, int accumulate,
+            int split_k, int64_t c_split_stride, void* stream);
+int sp_sum_slabs_f32(const float* partials, int S, int64_t n, int64_t slab_stride, float* out,
+                     int accumulate, const float* scale_dev, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

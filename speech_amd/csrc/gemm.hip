@@ -14,7 +14,7 @@
 // share an L2.
 #include <type_traits>
 
-#include "common.h"
+#include "gemm.h"
 
 namespace sp {
 
@@ -394,4 +394,42 @@ extern "C" int sp_gemm_nt_bf16(const void* A, const void* B, void* C, int M, int
         hipLaunchKernelGGL((gemm_nt_bf16_kernel<2>), dim3(grid), dim3(256), 0, s, (const __hip_bfloat16*)A,
                            (const __hip_bfloat16*)B, (__hip_bfloat16*)C, M, N, K, lda, ldb, ldc);
     return check_launch("gemm_nt_bf16_kernel");
+}
+
+// General entry point: see include/speech_hip.h.  The big K-contiguous bf16 problems go to the kernels
+// above, everything else to the general kernel (gemm_generic.hip).
+extern "C" int sp_gemm(const void* A, const void* B, void* C, int M, int N, int K, int64_t sam, int64_t sak,
+                       int64_t sbn, int64_t sbk, int64_t ldc, int in_dtype, int out_dtype, int accumulate,
+                       int split_k, int64_t c_split_stride, void* stream) {
+    using namespace sp;
+    SP_CHECK_ARG(M >= 0 && N >= 0 && K >= 0, "sp_gemm: bad shape M=%d N=%d K=%d", M, N, K);
+    SP_CHECK_ARG(in_dtype == SP_F32 || in_dtype == SP_F16 || in_dtype == SP_BF16, "sp_gemm: in_dtype %d", in_dtype);
+    SP_CHECK_ARG(out_dtype == SP_F32 || out_dtype == SP_F16 || out_dtype == SP_BF16, "sp_gemm: out_dtype %d", out_dtype);
+    SP_CHECK_ARG(sak == 1 || sam == 1, "sp_gemm: A must be contiguous along k (sak == 1) or along m (sam == 1)");
+    SP_CHECK_ARG(sbk == 1 || sbn == 1, "sp_gemm: B must be contiguous along k (sbk == 1) or along n (sbn == 1)");
+    SP_CHECK_ARG(!(sak == 1 && sam == 1 && M > 1 && K > 1) && !(sbk == 1 && sbn == 1 && N > 1 && K > 1),
+                 "sp_gemm: overlapping operand strides");
+    SP_CHECK_ARG(ldc >= N, "sp_gemm: ldc %lld < N %d", (long long)ldc, N);
+    SP_CHECK_ARG(split_k >= 1 && split_k <= 64, "sp_gemm: split_k %d outside [1, 64]", split_k);
+    SP_CHECK_ARG(!accumulate || out_dtype == SP_F32, "sp_gemm: accumulation needs an f32 output");
+    SP_CHECK_ARG(split_k == 1 || c_split_stride >= (int64_t)M * ldc,
+                 "sp_gemm: split-K slabs must not overlap (c_split_stride >= M * ldc)");
+    if (M == 0 || N == 0) return SP_OK;
+    SP_CHECK_ARG(C && (K == 0 || (A && B)), "sp_gemm: null pointer");
+    hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+    const int vec = in_dtype == SP_F32 ? 4 : 8;
+    const int64_t a_ld = sak == 1 ? sam : sak, b_ld = sbk == 1 ? sbn : sbk;
+    const bool aligned_in = (((uintptr_t)A | (uintptr_t)B) & 15) == 0 && a_ld % vec == 0 && b_ld % vec == 0;
+    // the fast kernels: both operands K-contiguous, bf16 in and out, whole tiles in N and K
+    if (sak == 1 && sbk == 1 && in_dtype == SP_BF16 && out_dtype == SP_BF16 && !accumulate && split_k == 1 &&
+        aligned_in && M >= 512 && N % 128 == 0 && K % kBK == 0 && K >= kBK && ldc % 4 == 0 && ((uintptr_t)C & 7) == 0 &&
+        sam >= K && sbn >= K)
+        return sp_gemm_nt_bf16(A, B, C, M, N, K, sam, sbn, ldc, stream);
+    GemmArgs g;
+    g.A = A; g.B = B; g.C = C; g.M = M; g.N = N; g.K = K;
+    g.sam = sam; g.sak = sak; g.sbn = sbn; g.sbk = sbk; g.ldc = ldc;
+    g.out_dtype = out_dtype; g.accumulate = accumulate; g.split_k = split_k; g.c_split_stride = c_split_stride;
+    g.vec_in = aligned_in;
+    SP_CHECK_ARG((int64_t)((M + 127) / 128) < 65536, "sp_gemm: M too large for the general kernel");
+    return gemm_generic(g, in_dtype, s);
 }

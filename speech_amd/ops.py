@@ -1,7 +1,9 @@
-"""Tensor-level wrappers over the C ABI (libspeech_hip.so).  torch supplies device memory and
-the current HIP stream; every computation below runs in the hand-written gfx950 kernels."""
+"""Tensor-level wrappers over the C ABI (libspeech_hip.so).  torch supplies device memory, the
+current HIP stream and the autograd graph; the arithmetic of the hot path -- frontend, convolutions,
+normalisations, every matrix product, recurrence, CTC, decode -- runs in the hand-written gfx950
+kernels.  What is left to torch are dtype casts and scalings of parameter-sized tensors and the
+dropout masks' random draws."""
 import ctypes
-import os as _os
 
 import numpy as np
 import torch
@@ -315,8 +317,50 @@ def layernorm_bwd(gy2d, x2d, mean, rstd, gamma, gres2d=None, dgamma=None, dbeta=
     return gx, dgamma, dbeta
 
 
+def gemm(a, b, out=None, out_dtype=None, accumulate=False, split_k=1):
+    """a [M, K] times b[N, K]^T -> [M, N] (sp_gemm, f32 accumulation).  a and b are VIEWS: each must be
+    contiguous along k or along its row index, so ``gemm(x, w.t())`` is x @ w and ``gemm(x.t(), g.t())``
+    is x^T g without any copy.  out_dtype: float32 / bfloat16 / float16 (default: a's dtype).
+    accumulate (f32 out): out += product.  split_k = S > 1: returns S partial products [S, M, N]."""
+    _need_cuda(a, "a")
+    M, K = a.shape
+    N = b.shape[0]
+    if b.shape[1] != K or a.dtype != b.dtype or a.dtype not in (torch.float32, torch.bfloat16, torch.float16):
+        raise ValueError(f"gemm: operands [M,K] and [N,K] of one float dtype expected, got {tuple(a.shape)} "
+                         f"{a.dtype} and {tuple(b.shape)} {b.dtype}")
+    if out_dtype is None:
+        out_dtype = out.dtype if out is not None else a.dtype
+
+    def strides(t):      # a dimension of extent 1 may carry any stride
+        s0, s1 = t.stride()
+        if t.shape[1] == 1 and s0 != 1:
+            s1 = 1
+        if t.shape[0] == 1 and s1 != 1:
+            s0 = 1
+        return s0, s1
+    sam, sak = strides(a)
+    sbn, sbk = strides(b)
+    if 1 not in (sam, sak):
+        a = a.contiguous()
+        sam, sak = a.stride()
+    if 1 not in (sbn, sbk):
+        b = b.contiguous()
+        sbn, sbk = b.stride()
+    if out is None:
+        shape = (M, N) if split_k == 1 else (split_k, M, N)
+        out = torch.empty(shape, dtype=out_dtype, device=a.device)
+    elif out.dtype != out_dtype or out.stride(-1) != 1:
+        raise ValueError("gemm: out must have out_dtype and unit column stride")
+    ldc = out.stride(-2) if M > 1 else max(N, 1)
+    css = out.stride(0) if split_k > 1 else 0
+    with torch.cuda.device(a.device):
+        check(lib().sp_gemm(ptr(a), ptr(b), ptr(out), M, N, K, sam, sak, sbn, sbk, ldc, _lib.dtype_code(a),
+                            _lib.dtype_code(out), int(accumulate), split_k, css, stream_ptr()), "sp_gemm")
+    return out
+
+
 def gemm_nt(a, b, out=None):
-    """a [M,K] @ b[N,K]^T -> [M,N], bf16, on the hand-written MFMA kernel (sp_gemm_nt_bf16)."""
+    """a [M,K] @ b[N,K]^T -> [M,N] on the bf16 K-contiguous kernels directly (sp_gemm_nt_bf16)."""
     _need_cuda(a, "a")
     M, K = a.shape
     N = b.shape[0]
@@ -329,6 +373,20 @@ def gemm_nt(a, b, out=None):
     with torch.cuda.device(a.device):
         check(lib().sp_gemm_nt_bf16(ptr(a), ptr(b), ptr(out), M, N, K, a.stride(0), b.stride(0), out.stride(0),
                                     stream_ptr()), "sp_gemm_nt_bf16")
+    return out
+
+
+def sum_slabs(partials, out=None, accumulate=False, scale=None):
+    """partials [S, ...] f32 -> sum over S (times the device scalar `scale`), written or added to `out`."""
+    S = partials.shape[0]
+    n = partials[0].numel()
+    if out is None:
+        out = torch.empty(partials.shape[1:], dtype=torch.float32, device=partials.device)
+    if scale is not None:
+        scale = scale.detach().reshape(-1)[:1].float().contiguous()
+    with torch.cuda.device(partials.device):
+        check(lib().sp_sum_slabs_f32(ptr(partials), S, n, partials.stride(0), ptr(out), int(accumulate), ptr(scale),
+                                     stream_ptr()), "sp_sum_slabs_f32")
     return out
 
 
@@ -427,70 +485,58 @@ def sru_unpack_dw(partials, n_in, d, k, C, out=None):
     return out
 
 
-_bmm_f32_out = None
-
-
 def _splitk_dw(xn, gU2, S):
-    """dW partials [S, n_in, N] of xn^T gU: the library GEMM has only n_in/256 * N/256 = 48 output
-    tiles for 256 CUs at the reference's sizes, so K (= T*B) is split S ways as a batched GEMM;
-    partials in f32 when the library can write them."""
-    global _bmm_f32_out
-    M, n_in = xn.shape
-    a = xn.view(S, M // S, n_in).transpose(1, 2)
-    b = gU2.view(S, M // S, -1)
-    if xn.dtype == torch.float32:
-        return torch.bmm(a, b)
-    if _bmm_f32_out is None:
-        try:
-            torch.bmm(a[:, :8, :8], b[:, :8, :8], out_dtype=torch.float32)
-            _bmm_f32_out = True
-        except (TypeError, RuntimeError):
-            _bmm_f32_out = False
-    return torch.bmm(a, b, out_dtype=torch.float32) if _bmm_f32_out else torch.bmm(a, b)
+    """f32 partials [S, n_in, N] of xn^T gU: the output has only n_in/256 * N/256 = 48 tiles for 256
+    CUs at the reference's sizes, so K (= T*B) is split S ways into slabs (no atomics; the slabs are
+    summed by sp_sru_unpack_dw / sp_sum_slabs_f32)."""
+    out = gemm(xn.t(), gU2.t(), out_dtype=torch.float32, split_k=S)
+    return out if S > 1 else out.unsqueeze(0)
 
 
-_mm_f32_out = None
+def _dw_splits(M):
+    return 8 if M >= 8192 else (4 if M >= 2048 else 1)
 
 
 def _classifier_logits(x2d, weight):
-    """(f32 logits [M, V], the weight in the activation dtype)."""
-    global _mm_f32_out
+    """(f32 logits [M, V] straight from the GEMM's f32 accumulators, the weight in the activation dtype)."""
     wb = weight.detach().to(x2d.dtype)
-    if x2d.dtype == torch.float32:
-        return torch.mm(x2d, wb.t()), wb
-    if _mm_f32_out is None:
-        try:
-            torch.mm(x2d[:8], wb[:8].t(), out_dtype=torch.float32)
-            _mm_f32_out = True
-        except (TypeError, RuntimeError):
-            _mm_f32_out = False
-    out = torch.mm(x2d, wb.t(), out_dtype=torch.float32) if _mm_f32_out else torch.mm(x2d, wb.t()).float()
-    return out, wb
+    return gemm(x2d, wb, out_dtype=torch.float32), wb
+
+
+def _classifier_dw(gb, x2d, weight, scale=None):
+    """Weight gradient g^T x of the classifier -- a [V, n] output with K = T'*B, split over the rows into
+    slabs that are summed (times the incoming loss gradient) straight into the parameter's gradient
+    buffer when the step owns one (GradSink); returns None then, else the gradient tensor."""
+    P = _splitk_dw(gb, x2d, _dw_splits(x2d.shape[0]))
+    sink = _sink
+    if sink is not None and sink.ok(weight) and P[0].numel() % 4 == 0:
+        sum_slabs(P, weight.grad, True, scale)
+        sink.ready(weight)
+        return None
+    if P[0].numel() % 4 == 0:
+        return sum_slabs(P, None, False, scale).to(weight.dtype)
+    gw = P.sum(0)
+    return (gw * scale if scale is not None else gw).to(weight.dtype)
 
 
 class _ClassifierFn(torch.autograd.Function):
-    """logits = x W^T (net.py:73-76, Linear without bias) with the two things the library's default
-    path does badly at these shapes handled by hand: the logits leave the GEMM in f32 (the CTC kernels
-    read f32; no bf16 round trip and no conversion pass over [B*T', V]), and the weight gradient
-    g^T x -- a [V, n] output, 16 tiles for 256 CUs -- is split 8 ways over the rows as one batched GEMM
-    with f32 partials."""
+    """logits = x W^T (net.py:73-76, Linear without bias): the logits leave the GEMM in f32 (the CTC
+    kernels read f32; no bf16 round trip and no conversion pass over [B*T', V]), and the weight gradient
+    g^T x is a split-K GEMM."""
 
     @staticmethod
     def forward(ctx, x2d, weight):
         out, wb = _classifier_logits(x2d, weight)
         ctx.save_for_backward(x2d, wb)
-        ctx.wdtype = weight.dtype
+        ctx.weight = weight
         return out
 
     @staticmethod
     def backward(ctx, g):
         x2d, wb = ctx.saved_tensors
         gb = g.to(x2d.dtype).contiguous()
-        gx = torch.mm(gb, wb)
-        M = x2d.shape[0]
-        S = 8 if (M % 8 == 0 and M >= 8192) else 1
-        gw = _splitk_dw(gb, x2d, S).sum(0) if S > 1 else torch.mm(gb.t(), x2d)
-        return gx, gw.to(ctx.wdtype)
+        gx = gemm(gb, wb.t())
+        return gx, _classifier_dw(gb, x2d, ctx.weight)
 
 
 class _HeadCTCFn(torch.autograd.Function):
@@ -506,7 +552,7 @@ class _HeadCTCFn(torch.autograd.Function):
         x2d = x_tm.reshape(T * B, n)
         logits, wb = _classifier_logits(x2d, weight)
         logits = logits.view(T, B, -1)
-        ctx.wdtype = weight.dtype
+        ctx.weight = weight
         il = torch.full((B,), T, dtype=torch.int32, device=x_tm.device)        # train.py:72-74: all T' frames
         loss, _, grad = ctc_fwd_bwd(logits, labels, il, label_lengths, blank, max_label_len, True, 1.0, True,
                                     x2d.dtype)            # the gradient leaves the kernel in the GEMMs' dtype
@@ -517,11 +563,8 @@ class _HeadCTCFn(torch.autograd.Function):
     @staticmethod
     def backward(ctx, g):
         x2d, wb, gb = ctx.saved_tensors
-        gx = torch.mm(gb, (wb.float() * g).to(wb.dtype))
-        M = x2d.shape[0]
-        S = 8 if (M % 8 == 0 and M >= 8192) else 1
-        gw = _splitk_dw(gb, x2d, S).sum(0) if S > 1 else torch.mm(gb.t(), x2d).float()
-        return gx.view(ctx.shape), (gw * g).to(ctx.wdtype), None, None, None, None
+        gx = gemm(gb, (wb.float() * g).to(wb.dtype).t())
+        return gx.view(ctx.shape), _classifier_dw(gb, x2d, ctx.weight, g), None, None, None, None
 
 
 def classifier_ctc_loss(x_tm, weight, labels, label_lengths, blank=0, max_label_len=None):
@@ -539,27 +582,15 @@ def classifier(x, weight):
 def _nt_projection(M, n_in, N, d, dtype):
     """The big forward projections run as an NT GEMM on W^T with padded row pitches (sp_sru_pack_wt):
     bf16, output-heavy (N >= 2 n_in), enough rows for one 192-row tile per CU and column.  That layout
-    is worth 15 % on this GEMM whoever runs it (profiles/r01_gemm.md): the library's NN kernel on W
-    takes 172 us at the reference's sizes, its NT kernel on the padded W^T 148 us, sp_gemm_nt_bf16 150 us."""
-    if _os.environ.get("SPEECH_AMD_LIB_GEMM"):      # measurement switch: the library's NN call on W
-        return False
+    is worth 15 % on this GEMM (profiles/r01_gemm.md): K-contiguous rows of both operands are what the
+    LDS-DMA kernels stream, and the pitch padding keeps 256 CUs off a 2 KB row stride."""
     return (dtype == torch.bfloat16 and N % 256 == 0 and n_in % 64 == 0 and d % 64 == 0 and N >= 2 * n_in
             and (M // 192) * (N // 256) >= 256 and M * max(n_in, N) < (1 << 30))
 
 
-def projection_nt(xn, wkt):
-    """xn [M, n_in] @ wkt[N, n_in]^T.  The library's NT kernel by default -- measured 1.5-2 % faster than
-    the hand-written persistent kernel inside the training step and 25 % faster at the 77 k-row
-    inference shape -- or sp_gemm_nt_bf16 with SPEECH_AMD_OWN_GEMM=1."""
-    if _os.environ.get("SPEECH_AMD_OWN_GEMM"):
-        return gemm_nt(xn, wkt)
-    return torch.mm(xn, wkt.t())
-
-
-
 class _SRULayerFn(torch.autograd.Function):
-    """One SRU layer (net.py:61-72): LayerNorm (HIP) -> projection GEMM (library) -> recurrence (HIP),
-    with a hand-ordered backward: recurrence backward, the two GEMMs (dW split-K), LayerNorm backward
+    """One SRU layer (net.py:61-72): LayerNorm -> projection GEMM -> recurrence, all HIP kernels, with
+    a hand-ordered backward: recurrence backward, the two GEMMs (dW split-K), LayerNorm backward
     fused with the highway's residual gradient.  x [T,B,n_in] with feature order f*C + c; ln_w, ln_b,
     weight are the state_dict parameters (f32, reference order); packing to the kernels' layout and the
     inverse for the gradients are HIP kernels (sp_sru_pack_w / sp_sru_unpack_dw)."""
@@ -580,14 +611,14 @@ class _SRULayerFn(torch.autograd.Function):
         train = any(ctx.needs_input_grad)      # False under no_grad: nothing is kept for a backward
         if own and train:      # W^T [N][n_in] for the forward (NT), W [n_in][N] for the data gradient
             wkt, wk = sru_pack_wt(w32, d, k, C, x.dtype, pad, both=True)
-            U = projection_nt(xn, wkt)
+            U = gemm(xn, wkt)
             del wkt
         elif own:
             wk = None
-            U = projection_nt(xn, sru_pack_wt(w32, d, k, C, x.dtype, pad))
+            U = gemm(xn, sru_pack_wt(w32, d, k, C, x.dtype, pad))
         else:        # wk holds W [n_in][N]
             wk = sru_pack_w(w32, d, k, C, x.dtype)
-            U = torch.mm(xn, wk)
+            U = gemm(xn, wk.t())
         wc32, bs32 = wc.detach().float().contiguous(), bias.detach().float().contiguous()
         xr = x2 if k == 3 else None
         h, c = sru_fwd(U, xr, wc32, bs32, mask, T, B, d, k, keep_c=train)
@@ -610,9 +641,8 @@ class _SRULayerFn(torch.autograd.Function):
                                         wc.grad.view(-1) if direct else None, bias.grad.view(-1) if direct else None)
         gU2 = gU.view(T * B, -1)
         M = T * B
-        S = 4 if (M % 4 == 0 and M >= 4096) else 1
-        gw = sru_unpack_dw(_splitk_dw(xn, gU2, S), n_in, d, k, C, weight.grad if direct else None)
-        gxn = torch.mm(gU2, wk.t())
+        gw = sru_unpack_dw(_splitk_dw(xn, gU2, 4 if M >= 4096 else 1), n_in, d, k, C, weight.grad if direct else None)
+        gxn = gemm(gU2, wk)
         gres = gxres.view(T * B, n_in) if k == 3 else None
         ln_direct = direct and C == 1   # layer 0's vectors are stored in the reference's c*F + f order
         gx, dg, db = layernorm_bwd(gxn, x2, mean, rstd, g32, gres, ln_w.grad if ln_direct else None,

@@ -55,6 +55,20 @@ def test_version_and_error_string():
     rc = h.sp_gemm_nt_bf16(8, 16, 16, 256, 128, 64, 64, 64, 128, None)
     assert rc == -1 and b"aligned" in h.sp_last_error()
     assert h.sp_gemm_nt_bf16(None, None, None, 0, 128, 64, 64, 64, 128, None) == 0      # M = 0: nothing to do
+    # the general GEMM: strides, dtypes, slabs
+    rc = h.sp_gemm(16, 16, 16, 8, 8, 8, 16, 2, 8, 1, 8, 2, 2, 0, 1, 0, None)
+    assert rc == -1 and b"contiguous along k" in h.sp_last_error()
+    rc = h.sp_gemm(16, 16, 16, 8, 8, 8, 8, 1, 8, 1, 4, 2, 2, 0, 1, 0, None)
+    assert rc == -1 and b"ldc" in h.sp_last_error()
+    rc = h.sp_gemm(16, 16, 16, 8, 8, 8, 8, 1, 8, 1, 8, 2, 2, 1, 1, 0, None)
+    assert rc == -1 and b"accumulation" in h.sp_last_error()
+    rc = h.sp_gemm(16, 16, 16, 8, 8, 8, 8, 1, 8, 1, 8, 2, 0, 0, 4, 8, None)
+    assert rc == -1 and b"slabs" in h.sp_last_error()
+    rc = h.sp_gemm(16, 16, 16, 8, 8, 8, 8, 1, 8, 1, 8, 5, 0, 0, 1, 0, None)
+    assert rc == -1 and b"in_dtype" in h.sp_last_error()
+    assert h.sp_gemm(None, None, None, 0, 8, 8, 8, 1, 8, 1, 8, 2, 2, 0, 1, 0, None) == 0
+    rc = h.sp_sum_slabs_f32(16, 2, 6, 8, 16, 0, None, None)
+    assert rc == -1 and b"multiples of 4" in h.sp_last_error()
     rc = h.sp_sru_pack_wt(16, 96, 64, 3, 1, 2, 16, 96, None, None)
     assert rc == -1 and b"n_in" in h.sp_last_error()                     # bf16 tiles are 64 rows
     rc = h.sp_sru_pack_wt(16, 128, 64, 3, 1, 2, 16, 100, None, None)

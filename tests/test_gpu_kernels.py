@@ -677,3 +677,67 @@ def test_gemm_nt_bf16(cuda, M, N, K):
         out3 = torch.empty(M, N + 8, dtype=torch.bfloat16, device=cuda)
         ops.gemm_nt(aw[:, 32:32 + K].contiguous(), b, out=out3[:, :N])
         assert torch.equal(out2, out3[:, :N])
+
+
+@pytest.mark.parametrize("form", ["nt", "nn", "tn", "tt"])
+@pytest.mark.parametrize("dtype,M,N,K", [
+    (torch.bfloat16, 393, 768, 256),       # T'=131 x B=3 rows: ragged in M
+    (torch.bfloat16, 300, 29, 1024),       # char-vocabulary classifier: N = 29
+    (torch.bfloat16, 257, 1000, 72),       # K not a multiple of the K step
+    (torch.float16, 130, 136, 200),
+    (torch.float32, 393, 384, 128),
+    (torch.float32, 65, 29, 100),
+    (torch.bfloat16, 1, 8, 8),
+])
+def test_gemm_general(cuda, form, dtype, M, N, K):
+    """sp_gemm (the general MFMA kernel) in all four operand forms against an f64 matmul of the same
+    inputs: f32 accumulation, so the error is the output rounding (f32 out: accumulation order only)."""
+    from speech_amd import ops
+    g = torch.Generator().manual_seed(M * 7 + N * 3 + K)
+    a = torch.randn(M, K, generator=g).to(dtype).to(cuda)
+    b = torch.randn(N, K, generator=g).to(dtype).to(cuda)
+    av = a if form[0] == "n" else a.t().contiguous().t()          # same values, m-contiguous storage
+    bv = b if form[1] == "t" else b.t().contiguous().t()          # "n": B stored [K][N]
+    ref = a.double() @ b.double().t()
+    out32 = ops.gemm(av, bv, out_dtype=torch.float32)
+    tol = 1e-5 if dtype == torch.float32 else 2e-6 * K ** 0.5 + 1e-6
+    assert float((out32.double() - ref).abs().max()) <= tol * float(ref.abs().max()) + 1e-6
+    if dtype != torch.float32:
+        out = ops.gemm(av, bv)
+        assert out.dtype == dtype
+        eps = 2.0 ** -8 if dtype == torch.bfloat16 else 2.0 ** -11
+        assert float((out.double() - ref).abs().max()) <= eps * float(ref.abs().max()) + 1e-6
+    # split-K slabs sum to the product; accumulation adds to what is there
+    S = 3
+    slabs = ops.gemm(av, bv, out_dtype=torch.float32, split_k=S)
+    assert tuple(slabs.shape) == (S, M, N)
+    assert float((slabs.double().sum(0) - ref).abs().max()) <= tol * float(ref.abs().max()) + 1e-6
+    base = torch.randn(M, N, generator=g).to(cuda)
+    acc = base.clone()
+    ops.gemm(av, bv, out=acc, accumulate=True)
+    assert float((acc.double() - base.double() - ref).abs().max()) <= 2 * tol * float(ref.abs().max()) + 1e-5
+    if (M * N) % 4 == 0:
+        tgt = base.clone()
+        sc = torch.tensor([0.5], device=cuda)
+        ops.sum_slabs(slabs, tgt, True, sc)
+        assert float((tgt.double() - base.double() - 0.5 * ref).abs().max()) <= 2 * tol * float(ref.abs().max()) + 1e-5
+
+
+def test_gemm_general_unaligned_and_strided(cuda):
+    """Row pitches that are not multiples of a 16-byte vector fall back to element-wise loads; padded
+    pitches and an offset output view are honoured."""
+    from speech_amd import ops
+    g = torch.Generator().manual_seed(11)
+    M, N, K = 77, 45, 29
+    a = torch.randn(M, K, generator=g).bfloat16().to(cuda)            # pitch 29 elements
+    b = torch.randn(N, K, generator=g).bfloat16().to(cuda)
+    ref = a.double() @ b.double().t()
+    out = ops.gemm(a, b, out_dtype=torch.float32)
+    assert float((out.double() - ref).abs().max()) <= 1e-5 * float(ref.abs().max())
+    wide = torch.zeros(M, 64, device=cuda)
+    ops.gemm(a, b, out=wide[:, 8:8 + N])
+    assert float((wide[:, 8:8 + N].double() - ref).abs().max()) <= 1e-5 * float(ref.abs().max())
+    assert float(wide[:, :8].abs().max()) == 0 and float(wide[:, 8 + N:].abs().max()) == 0
+    ap = torch.zeros(M, 40, device=cuda).bfloat16()
+    ap[:, :K] = a
+    assert torch.equal(ops.gemm(ap[:, :K], b, out_dtype=torch.float32), out)

@@ -5,6 +5,7 @@ BASELINE.json configs[1]: synthetic 16 kHz audio, batch 32 x 15 s per GPU, 80 me
 sized vocabulary (999 pieces + blank), bf16 activations.
 
     python bench.py --gpus 1 --steps 20 --warmup 5
+    python bench.py --gpus N ...          # starts N rank processes itself (one per GPU, RCCL)
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \\
         --master-port P bench.py --gpus N --steps K --warmup W
 
@@ -35,7 +36,6 @@ PMC_TRAFFIC_BYTES = {
     ("sru_fwd_kernel", "bf16", 32, 15.0): 2 * 96184.9 * 1024 + 96128.0 * 1024,
     # L2-miss side of the forward GEMM (tools/pmc_gemm.py fwd): B panels stay L2-resident per XCD, A is
     # streamed once per owning XCD; algorithmic 55.5 MB read + 147.7 MB written
-    ("gemm_nt_bf16(forward projection)", "bf16", 32, 15.0): 2 * 140472.0 * 1024 + 144192.0 * 1024,
 }
 MFMA_BF16_PEAK_TF = 2500.0  # dense bf16
 
@@ -52,6 +52,15 @@ def parse():
     p.add_argument("--no-cpu-baseline", action="store_true")
     p.add_argument("--kernel-iters", type=int, default=20)
     return p.parse_args()
+
+
+def _config_name(B, seconds):
+    """Which BASELINE.json config the arguments are."""
+    if B == 32 and seconds == 15.0:
+        return "configs[1]"
+    if B == 64 and seconds == 30.0:
+        return "configs[3] (long-form)"
+    return "custom shape"
 
 
 def synth_batch(B, N, V, seconds, device, vocab):
@@ -189,26 +198,37 @@ def _in_step_events(step_fn, name, key, n_steps=2):
 
 
 def gemm_in_step(step_fn, n_steps=2):
-    """Live duration of the hand-written forward-projection GEMM INSIDE the training step (only when
-    SPEECH_AMD_OWN_GEMM=1 puts it there; the default engine of that GEMM is the library's NT kernel).
-    A back-to-back microbenchmark of a dense-MFMA kernel is not representative (the clock sags within
-    milliseconds of continuous MFMA load, and the caches hold other data than in the step)."""
-    by_shape = _in_step_events(step_fn, "gemm_nt", lambda a, b, out=None: (a.shape[0], b.shape[0], a.shape[1]), n_steps)
-    if not by_shape:
-        return None
-    (M, N, K), ts = max(by_shape.items(), key=lambda kv: len(kv[1]))      # the nine 1024 -> 3072 layers
-    ms, fl = sum(ts) / len(ts), 2.0 * M * N * K
-    return {"bound": "mfma", "achieved": fl / ms / 1e9, "peak": MFMA_BF16_PEAK_TF, "unit": "TFLOP/s",
-            "frac": fl / ms / 1e9 / MFMA_BF16_PEAK_TF, "ms": ms, "algorithmic_flops": fl,
-            "algorithmic_bytes": 2 * (M * K + N * K + M * N), "launches_per_step": len(ts) // n_steps,
-            "shape_mnk": [M, N, K], "timed": "in-step, one HIP event pair per launch"}
+    """Live durations of the projection GEMMs INSIDE the training step, one HIP event pair per launch on the
+    launch stream (a back-to-back microbenchmark of a dense-MFMA kernel is not representative: the clock sags
+    within milliseconds of continuous MFMA load, and the caches hold other data than in the step).  Returns
+    {name: roofline line} for the three 1024 <-> 3072 products of the nine k = 3 SRU layers."""
+    def key(a, b, out=None, out_dtype=None, accumulate=False, split_k=1):
+        form = "nt" if a.stride(-1) == 1 and b.stride(-1) == 1 else ("tn" if a.stride(0) == 1 and b.stride(0) == 1 else "other")
+        return (form, a.shape[0], b.shape[0], a.shape[1])
+    by_shape = _in_step_events(step_fn, "gemm", key, n_steps)
+    names = {("nt", 3072, 1024): "gemm_nt(forward projection U = LN(x) W)", ("nt", 1024, 3072): "gemm_nt(data gradient gX = gU W^T)",
+             ("tn", 3072, None): "gemm_tn(weight gradient dW = LN(x)^T gU, split-K)"}
+    out = {}
+    for (form, M, N, K), ts in by_shape.items():
+        name = names.get((form, N, K)) or (names.get((form, N, None)) if form == "tn" and M == 1024 else None)
+        if name is None:
+            continue
+        ms, fl = sum(ts) / len(ts), 2.0 * M * N * K
+        out[name] = {"bound": "mfma", "achieved": fl / ms / 1e9, "peak": MFMA_BF16_PEAK_TF, "unit": "TFLOP/s",
+                     "frac": fl / ms / 1e9 / MFMA_BF16_PEAK_TF, "ms": ms, "algorithmic_flops": fl,
+                     "algorithmic_bytes": 2 * (M * K + N * K + M * N), "launches_per_step": len(ts) // n_steps,
+                     "shape_mnk": [M, N, K], "timed": "in-step, one HIP event pair per launch"}
+    return out
 
 
-def sru_bwd_in_step(step_fn, n_steps=2):
-    """Average duration of the k = 3 SRU backward launches inside the training step (the event pair
-    brackets the one kernel sp_sru_bwd launches)."""
-    by_k = _in_step_events(step_fn, "sru_bwd", lambda U, xres, wc, bias, mask, c, gh, T, B, d, k, *r, **kw: k, n_steps)
-    ts = by_k.get(3)
+def sru_in_step(step_fn, which, n_steps=2):
+    """Average duration of the k = 3 SRU recurrence launches (which = "sru_fwd" / "sru_bwd") inside the
+    training step (the event pair brackets the one kernel the call launches)."""
+    if which == "sru_bwd":
+        key = lambda U, xres, wc, bias, mask, c, gh, T, B, d, k, *r, **kw: k      # noqa: E731
+    else:
+        key = lambda U, xres, wc, bias, mask, T, B, d, k, *r, **kw: k            # noqa: E731
+    ts = _in_step_events(step_fn, which, key, n_steps).get(3)
     return (sum(ts) / len(ts), len(ts) // n_steps) if ts else None
 
 
@@ -244,6 +264,27 @@ def cpu_baseline(args, V):
                       f"torch conv/BN/GEMM, python-loop SRU, torch CTC, torch Adam), {dt:.1f} s wall"}
 
 
+def spawn_ranks(n):
+    """`python bench.py --gpus N` typed as is: start N fresh rank processes of this script (one per GPU, the
+    launcher's environment contract: RANK / LOCAL_RANK / WORLD_SIZE / MASTER_ADDR / MASTER_PORT) and relay rank 0's
+    JSON line.  Nothing in this process has touched the GPU, and nothing is exec'ed: the ranks are children."""
+    import socket
+    import subprocess
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), MASTER_ADDR="127.0.0.1",
+                   MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
+                                      stdout=None if r == 0 else subprocess.DEVNULL))
+    rc = 0
+    for p in procs:
+        rc = p.wait() or rc
+    return rc
+
+
 def main():
     args = parse()
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -252,7 +293,7 @@ def main():
     if world != args.gpus and world > 1:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
     if args.gpus > 1 and world == 1:
-        raise SystemExit("launch multi-GPU runs with torch.distributed.run (one process per GPU)")
+        raise SystemExit(spawn_ranks(args.gpus))
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     if world > 1:
@@ -306,7 +347,7 @@ def main():
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1000.0 * dt / args.steps,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": args.dtype,
             "data": "synthetic",
-            "config": {"workload": f"configs[1]: synthetic 16 kHz, batch {B} x {args.seconds:g} s per GPU, 80 mels, "
+            "config": {"workload": f"{_config_name(B, args.seconds)}: synthetic 16 kHz, batch {B} x {args.seconds:g} s per GPU, 80 mels, "
                                    f"{'sentencepiece-sized vocab (999+blank)' if args.vocab == 'sp' else 'char vocab (29)'}"
                                    ", full training step (mel frontend + SRModel fwd/bwd + CTC + clip + Adam)",
                        "global_batch": B * world, "seconds_per_utt": args.seconds, "vocab": V,
@@ -314,17 +355,18 @@ def main():
         }
         if world == 1:
             ks = kernel_rooflines(args, model, wav, offs, labels, lens, Lmax, V, args.kernel_iters)
-            g = gemm_in_step(step) if args.dtype == "bf16" else None
-            if g is not None:
-                ks["gemm_nt_bf16(forward projection)"] = g
-            sb = sru_bwd_in_step(step) if args.dtype == "bf16" else None
-            if sb is not None:      # replace the stand-alone timing by the in-step one
-                k = ks["sru_bwd_kernel"]
-                k["ms_standalone"], k["ms"], k["timed"] = k["ms"], sb[0], "in-step, one HIP event pair per launch"
-                k["achieved"] = k["algorithmic_bytes"] / sb[0] / 1e6
-                k["frac"] = k["achieved"] / HBM_PEAK_GBS
-                k["launches_per_step"] = sb[1] + 1      # + the k = 4 first layer
-            # dominant = the hand-written kernel with the largest share of the training step
+            if args.dtype == "bf16":
+                ks.update(gemm_in_step(step))
+                for which in ("sru_fwd", "sru_bwd"):      # replace the stand-alone timings by the in-step ones
+                    sb = sru_in_step(step, which)
+                    if sb is not None:
+                        k = ks[which + "_kernel"]
+                        k["ms_standalone"], k["ms"], k["timed"] = k["ms"], sb[0], "in-step, one HIP event pair per launch"
+                        k["achieved"] = k["algorithmic_bytes"] / sb[0] / 1e6
+                        k["frac"] = k["achieved"] / HBM_PEAK_GBS
+                        k["launches_per_step"] = sb[1] + 1      # + the k = 4 first layer
+            # dominant = the kernel with the largest share of the training step, over ALL kernels timed here
+            # (every kernel of the step is hand-written; the three projection GEMMs lead)
             dom = max(ks, key=lambda k: ks[k]["ms"] * ks[k]["launches_per_step"])
             r = dict(ks[dom])
             r["kernel"] = dom

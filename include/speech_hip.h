@@ -224,7 +224,7 @@ int sp_block_bwd_in(const void* gz, const void* z, int64_t zsb, int64_t zsf, int
  * inverse for the gradient, summing S split-K partials [S][n_in][k][dir][d] of dtype into f32
  * dweight[n_in][dir][d][k] (overwritten, or added to when accumulate != 0: the caller's gradient
  * buffer).  sp_sru_pack_wt: the same weight transposed, WkT[k][dir][d][n_in] with row pitch ldo elements
- * (>= n_in, even): the K-contiguous B operand of sp_gemm_nt_bf16 for the forward projection; with out_w
+ * (>= n_in, even): the K-contiguous B operand of sp_gemm for the forward projection; with out_w
  * != NULL the same pass also writes sp_sru_pack_w's Wk there (what the data gradient's GEMM reads).
  * n_in % 64 == 0 (bf16; 32 for f32), d % 64 == 0. */
 int sp_sru_pack_w(const float* weight, int n_in, int d, int k, int C, int dtype, void* out, void* stream);
@@ -240,25 +240,13 @@ int sp_sru_unpack_dw(const void* partials, int S, int n_in, int d, int k, int C,
  * Backward: gx = LN'(gy) (+ gres if not NULL: the SRU highway's residual gradient);
  * dgamma / dbeta are ACCUMULATED (caller zeroes).  ldy: row pitch of y in elements (>= N, multiple
  * of 8; N for a dense output) -- a pitch that is not a multiple of 1024 bytes keeps the GEMM that
- * reads y off the L2-channel conflicts of power-of-two row strides.
+ * reads y off the L2-channel conflicts of power-of-two row strides (measured 11 % on the forward projection).
  * --------------------------------------------------------------------------------------- */
 int sp_layernorm_fwd(const void* x, const float* gamma, const float* beta, int64_t M, int N, float eps,
                      int dtype, void* y, int64_t ldy, float* mean, float* rstd, void* stream);
 int sp_layernorm_bwd(const void* gy, const void* x, const float* mean, const float* rstd,
                      const float* gamma, const void* gres, int64_t M, int N, int dtype, void* gx,
                      float* dgamma, float* dbeta, void* stream);
-
-/* ---------------------------------------------------------------------------------------
- * bf16 GEMM, both operands K-contiguous ("NT"): C[M][N] = A[M][K] * B[N][K]^T, f32 accumulate,
- * bf16 out.  Replaces the SRU forward projection matmul of net.py:61-72 (sru.SRU: U = LN(x) W, with
- * W^T from sp_sru_pack_wt); also correct for the data gradient gX = gU W^T.  N % 128 == 0,
- * K % 32 == 0, leading dimensions in elements (multiples of 8 for A and B, of 4 for C), 16-byte
- * aligned bases.  Shapes with N % 256 == 0, K % 64 == 0, ldc % 8 == 0 and at least 256 tiles of
- * 192 x 256 run on the persistent kernel (one workgroup per CU); row pitches that are not multiples
- * of 1 KB avoid L2-channel conflicts (measured 11 % on the forward projection).
- * --------------------------------------------------------------------------------------- */
-int sp_gemm_nt_bf16(const void* A, const void* B, void* C, int M, int N, int K, int64_t lda, int64_t ldb,
-                    int64_t ldc, void* stream);
 
 /* ---------------------------------------------------------------------------------------
  * General GEMM on the matrix cores, f32 accumulation:
@@ -276,6 +264,9 @@ int sp_gemm_nt_bf16(const void* A, const void* B, void* C, int M, int N, int K, 
  * problems with both operands K-contiguous (and, for the weight gradient, both row-contiguous) run on
  * the persistent LDS-DMA kernels of csrc/gemm.hip; which kernel runs is decided by the shape alone.
  *
+ * sp_gemm_tn_splits: the split_k this library would choose for a weight-gradient product (A and B both
+ * row-contiguous, K = M, N, K as passed to sp_gemm): enough K ranges to give every CU a 256 x 256 tile.
+ *
  * sp_sum_slabs_f32: out[i] (+)= scale * sum_s partials[s * slab_stride + i], i < n (n, slab_stride
  * multiples of 4; scale_dev: device float or NULL = 1) -- the reduction of split-K slabs straight into a
  * gradient buffer, with the incoming loss gradient (a device scalar) folded in.
@@ -283,6 +274,7 @@ int sp_gemm_nt_bf16(const void* A, const void* B, void* C, int M, int N, int K, 
 int sp_gemm(const void* A, const void* B, void* C, int M, int N, int K, int64_t sam, int64_t sak,
             int64_t sbn, int64_t sbk, int64_t ldc, int in_dtype, int out_dtype, int accumulate,
             int split_k, int64_t c_split_stride, void* stream);
+int sp_gemm_tn_splits(int M, int N, int K, int in_dtype);
 int sp_sum_slabs_f32(const float* partials, int S, int64_t n, int64_t slab_stride, float* out,
                      int accumulate, const float* scale_dev, void* stream);
 

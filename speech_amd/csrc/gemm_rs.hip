@@ -1,0 +1,495 @@
+// Role-split persistent bf16 GEMMs for the SRU projections of net.py:61-72 and the classifier of
+// net.py:73-76 at training / bulk-inference sizes.
+//
+//   NT:  C[M][N] = A[M][K] * B[N][K]^T     (both operands K-contiguous: forward U = LN(x) W on the packed
+//        W^T, data gradient gX = gU W^T, classifier logits and their data gradient)
+//
+// One workgroup per CU, 12 waves with FIXED ROLES:
+//   * waves 0-7 ("compute", two per SIMD) own the MFMA work: fragments LDS -> registers by ds_read_b128,
+//     v_mfma_f32_16x16x32_bf16, and the epilogue stores.  They never wait on a vector-memory counter:
+//     their only vector-memory instructions are the C stores, which drain in the background while the
+//     next tile's K steps run.
+//   * waves 8-11 ("loaders", one per SIMD) own every global -> LDS transfer: LDS-DMA
+//     (global_load_lds_dwordx4) of whole 128-byte operand lines into a ring of K = 64 stages, a counted
+//     s_waitcnt vmcnt, and nothing else.  On gfx950 loads and stores retire in issue order per wave, so
+//     a wave that both stores C and waits for its next operand stage stalls on the stores'
+//     acknowledgements; with the roles split that wait only ever covers loads, and no MFMA wave spends
+//     issue slots on DMA instructions.
+// One s_barrier per K step hands a landed stage to the compute waves and a consumed stage back to the
+// loaders.  The workgroup walks its tiles as ONE flat sequence of K steps (the loaders run ahead across
+// tile boundaries).  LDS rows are whole 128-byte lines with 16-byte chunk c of row r stored at chunk
+// c ^ ((r >> 1) & 7): conflict-free for the 16-lane groups of ds_read_b128; LDS-DMA writes lane-linear,
+// so the permutation is applied to the per-lane SOURCE address.  The MFMA takes the B rows as its row
+// operand and the A rows as its column operand: a lane ends up with 4 consecutive n of one m; two
+// v_permlane16_swap per pair of accumulators widen that to 16-byte stores (64 contiguous bytes per row
+// and instruction) without an LDS round trip.  Tile order is XCD-aware (see tile ownership below).
+#include "gemm.h"
+
+namespace sp {
+
+typedef __bf16 rs_bf16x8 __attribute__((ext_vector_type(8)));
+typedef float rs_f32x4 __attribute__((ext_vector_type(4)));
+typedef uint32_t rs_u32x4 __attribute__((ext_vector_type(4)));
+typedef __attribute__((address_space(1))) const void* rs_gptr_t;
+typedef __attribute__((address_space(3))) void* rs_lptr_t;
+
+int g_lab[8] = {0, 0, 0, 0, 0, 0, 0, 0};     // development knobs (sp_lab_set): [0] gcols override, [1] non-temporal C stores
+
+struct RsArgs {
+    const __hip_bfloat16* A; const __hip_bfloat16* B; void* C;
+    int M, N, K, lda, ldb;
+    int64_t ldc;
+    int ntn, ntm, gcols, nts;
+};
+
+// XCD-aware tile ownership.  The eight XCDs (workgroup b runs on XCD b % 8) form a gcols x (8 / gcols)
+// grid over the tile matrix: an XCD owns ntn / gcols whole tile COLUMNS of a contiguous range of tile
+// rows, so its share of B stays resident in its 4 MB L2 and every A panel it streams is used by all of
+// its columns back to back.  Its workgroups take the tiles of that sub-matrix round-robin, columns fastest.
+struct RsTiles {
+    int cols_per, col0, row_lo, run1, first, nslots, count;
+    __device__ __forceinline__ RsTiles(int ntn, int ntm, int gcols) {
+        const int xcd = blockIdx.x & 7;
+        nslots = gridDim.x >> 3;
+        cols_per = ntn / gcols;
+        const int grows = 8 / gcols;
+        col0 = (xcd % gcols) * cols_per;
+        row_lo = (int)((int64_t)(xcd / gcols) * ntm / grows);
+        const int row_hi = (int)((int64_t)(xcd / gcols + 1) * ntm / grows);
+        run1 = (row_hi - row_lo) * cols_per;
+        first = blockIdx.x >> 3;
+        count = first < run1 ? (run1 - first + nslots - 1) / nslots : 0;
+    }
+    __device__ __forceinline__ int tile_m(int i) const { return row_lo + i / cols_per; }
+    __device__ __forceinline__ int tile_n(int i) const { return col0 + i % cols_per; }
+};
+
+// BM x BN tile, WMW x WNW compute waves (= 8), NST ring stages of K = 64, OUT = SP_BF16 or SP_F32
+template <int BM, int BN, int WMW, int NST, int OUT, int ABL = 0>
+__global__ __launch_bounds__(768, 3) void gemm_nt_rs_kernel(RsArgs g) {
+    constexpr int WNW = 8 / WMW;
+    constexpr int TM = BM / WMW, TN = BN / WNW;          // wave tile
+    constexpr int MB = TM / 16, NB = TN / 16;
+    constexpr int ROWB = 128, STAGE = (BM + BN) * ROWB;
+    constexpr int GA = BM / 8, G = (BM + BN) / 8;        // 8-row DMA groups per stage
+    constexpr int PER = G / 4;                           // ... per loader wave
+    static_assert(G % 4 == 0 && GA % 4 == 0 && NB % 2 == 0 && TM % 16 == 0 && TN % 16 == 0, "tile shape");
+    static_assert(NST * STAGE <= 160 * 1024, "LDS");
+    __shared__ __attribute__((aligned(1024))) unsigned char smem[NST * STAGE];
+
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const RsTiles tl(g.ntn, g.ntm, g.gcols);
+    if (tl.count == 0) return;
+    const int nk = g.K / 64;
+    const int total = tl.count * nk;
+
+    if (wave >= 8) {
+        // ------------------------------------------------------------------ loader
+        const int lw = wave - 8;
+        const int drow = lane >> 3;
+        const int lchunk = (lane & 7) ^ (((lw & 1) << 2) | (drow >> 1));
+        int a_off[GA / 4], b_off[(G - GA) / 4];
+        int ltile = tl.first, lk = 0;
+        auto set_tile = [&](int tile) {
+            const int m0 = tl.tile_m(tile) * BM, n0 = tl.tile_n(tile) * BN;
+#pragma unroll
+            for (int i = 0; i < GA / 4; ++i)     // rows past M are never stored: clamp their source
+                a_off[i] = min(m0 + 8 * (lw + 4 * i) + drow, g.M - 1) * g.lda + lchunk * 8;
+#pragma unroll
+            for (int i = 0; i < (G - GA) / 4; ++i)
+                b_off[i] = (n0 + 8 * (lw + 4 * i) + drow) * g.ldb + lchunk * 8;
+        };
+        set_tile(ltile);
+        auto issue = [&](int stage) {
+            unsigned char* st = smem + stage * STAGE + lw * 1024;
+            if (ABL == 2) return;
+            const __hip_bfloat16* ap = g.A + lk * 64;
+            const __hip_bfloat16* bp = g.B + lk * 64;
+#pragma unroll
+            for (int i = 0; i < GA / 4; ++i)
+                __builtin_amdgcn_global_load_lds((rs_gptr_t)(ap + a_off[i]), (rs_lptr_t)(st + i * 4096), 16, 0, 0);
+#pragma unroll
+            for (int i = 0; i < (G - GA) / 4; ++i)
+                __builtin_amdgcn_global_load_lds((rs_gptr_t)(bp + b_off[i]), (rs_lptr_t)(st + BM * ROWB + i * 4096), 16, 0, 0);
+            if (++lk == nk) {
+                lk = 0;
+                ltile += tl.nslots;
+                if (ltile < tl.run1) set_tile(ltile);     // past the last tile: harmless re-loads keep vmcnt uniform
+            }
+        };
+#pragma unroll
+        for (int s = 0; s < NST - 1; ++s) issue(s);
+        int fill = NST - 1;                  // stage the next issue goes to
+        for (int step = 0; step < total; ++step) {
+            asm volatile("s_waitcnt vmcnt(%0)" ::"n"((NST - 2) * PER) : "memory");    // this wave's share of `step` landed
+            __builtin_amdgcn_s_barrier();    // B_step: stage of `step` is complete, stage of step - 1 is free
+            asm volatile("" ::: "memory");
+            issue(fill);                     // step + NST - 1
+            fill = fill + 1 == NST ? 0 : fill + 1;
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // nothing may land after the workgroup's LDS is released
+        return;
+    }
+
+    // ---------------------------------------------------------------------- compute
+    const int wm = wave / WNW, wn = wave % WNW;
+    const int li = lane & 15, q = lane >> 4;
+    const int swz = (li >> 1) & 7;
+    const unsigned char* sa0 = smem + (wm * TM + li) * ROWB;
+    const unsigned char* sb0 = smem + BM * ROWB + (wn * TN + li) * ROWB;
+    const int pc0 = ((0 + q) ^ swz) * 16, pc1 = ((4 + q) ^ swz) * 16;
+
+    rs_f32x4 acc[MB][NB];
+#pragma unroll
+    for (int a = 0; a < MB; ++a)
+#pragma unroll
+        for (int b = 0; b < NB; ++b) acc[a][b] = rs_f32x4{0.f, 0.f, 0.f, 0.f};
+
+    int ctile = tl.first, ck = 0, stage = 0;
+    for (int step = 0; step < total; ++step) {
+        __builtin_amdgcn_s_barrier();        // B_step
+        asm volatile("" ::: "memory");
+        const unsigned char* sa = sa0 + stage * STAGE;
+        const unsigned char* sb = sb0 + stage * STAGE;
+#pragma unroll
+        for (int kk = 0; kk < (ABL == 1 ? 0 : 2); ++kk) {
+            const int pc = kk ? pc1 : pc0;
+            rs_bf16x8 P[NB];
+#pragma unroll
+            for (int b = 0; b < NB; ++b) P[b] = __builtin_bit_cast(rs_bf16x8, *reinterpret_cast<const rs_u32x4*>(sb + b * 16 * ROWB + pc));
+#pragma unroll
+            for (int a = 0; a < MB; ++a) {
+                const rs_bf16x8 Q = __builtin_bit_cast(rs_bf16x8, *reinterpret_cast<const rs_u32x4*>(sa + a * 16 * ROWB + pc));
+#pragma unroll
+                for (int b = 0; b < NB; ++b) acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(P[b], Q, acc[a][b], 0, 0, 0);
+            }
+        }
+        asm volatile("" ::: "memory");
+        stage = stage + 1 == NST ? 0 : stage + 1;
+        if (++ck == nk) {
+            // D[row = n][col = m]: lane = (m = li, q), register e -> n = 4 q + e
+            const int m0 = tl.tile_m(ctile) * BM + wm * TM, n0 = tl.tile_n(ctile) * BN + wn * TN;
+#pragma unroll
+            for (int a = 0; a < MB; ++a) {
+                const int m = m0 + a * 16 + li;
+                if constexpr (OUT == SP_F32) {
+                    float* crow = reinterpret_cast<float*>(g.C) + (int64_t)m * g.ldc + n0 + 4 * q;
+                    if (m < g.M && ABL != 3) {
+#pragma unroll
+                        for (int b = 0; b < NB; ++b) {
+                            if (g.nts) __builtin_nontemporal_store(acc[a][b], reinterpret_cast<rs_f32x4*>(crow + b * 16));
+                            else *reinterpret_cast<rs_f32x4*>(crow + b * 16) = acc[a][b];
+                        }
+                    }
+                } else {
+                    __hip_bfloat16* crow = reinterpret_cast<__hip_bfloat16*>(g.C) + (int64_t)m * g.ldc + n0 + (q & 1) * 16 + (q >> 1) * 8;
+#pragma unroll
+                    for (int b = 0; b < NB; b += 2) {
+                        auto pk = [](float lo, float hi) {
+                            return (uint32_t)__builtin_bit_cast(unsigned short, __float2bfloat16(lo)) |
+                                   ((uint32_t)__builtin_bit_cast(unsigned short, __float2bfloat16(hi)) << 16);
+                        };
+                        const uint32_t x0 = pk(acc[a][b][0], acc[a][b][1]), x1 = pk(acc[a][b][2], acc[a][b][3]);
+                        const uint32_t y0 = pk(acc[a][b + 1][0], acc[a][b + 1][1]), y1 = pk(acc[a][b + 1][2], acc[a][b + 1][3]);
+                        // rows (16-lane groups) 1 and 3 of x trade places with rows 0 and 2 of y: every lane then
+                        // holds 8 consecutive n
+                        const auto s0 = __builtin_amdgcn_permlane16_swap(x0, y0, false, false);
+                        const auto s1 = __builtin_amdgcn_permlane16_swap(x1, y1, false, false);
+                        const rs_u32x4 o = rs_u32x4{s0[0], s1[0], s0[1], s1[1]};
+                        if (m < g.M && ABL != 3) {
+                            if (g.nts) __builtin_nontemporal_store(o, reinterpret_cast<rs_u32x4*>(crow + b * 16));
+                            else *reinterpret_cast<rs_u32x4*>(crow + b * 16) = o;
+                        }
+                    }
+                }
+#pragma unroll
+                for (int b = 0; b < NB; ++b) acc[a][b] = rs_f32x4{0.f, 0.f, 0.f, 0.f};
+            }
+            ck = 0;
+            ctile += tl.nslots;
+        }
+    }
+}
+
+template <int BM, int BN, int WMW, int NST, int ABL = 0>
+static int launch_nt_rs(const void* A, const void* B, void* C, int M, int N, int K, int64_t lda, int64_t ldb, int64_t ldc,
+                        int out_dtype, hipStream_t s) {
+    RsArgs g;
+    g.A = (const __hip_bfloat16*)A; g.B = (const __hip_bfloat16*)B; g.C = C;
+    g.M = M; g.N = N; g.K = K; g.lda = (int)lda; g.ldb = (int)ldb; g.ldc = ldc;
+    g.ntn = N / BN; g.ntm = (M + BM - 1) / BM;
+    // XCD grid gcols x (8 / gcols): every XCD streams its rows of A once and its columns of B once per round,
+    // so the traffic from beyond the L2s is about gcols * |A| + (8 / gcols) * |B|; take the cheapest split.
+    // (The data gradient, whose A = gU is 24x its B, wants gcols = 1: measured 170 -> 148 us.)
+    g.gcols = 1;
+    double best = -1;
+    for (int c = 1; c <= 8; c <<= 1) {
+        if (g.ntn % c) continue;
+        const double cost = (double)c * M * K + (8.0 / c) * N * K;
+        if (best < 0 || cost < best) best = cost, g.gcols = c;
+    }
+    if (g_lab[0] > 0 && g.ntn % g_lab[0] == 0) g.gcols = g_lab[0];
+    g.nts = g_lab[1];
+    if (out_dtype == SP_F32) hipLaunchKernelGGL((gemm_nt_rs_kernel<BM, BN, WMW, NST, SP_F32, ABL>), dim3(256), dim3(768), 0, s, g);
+    else hipLaunchKernelGGL((gemm_nt_rs_kernel<BM, BN, WMW, NST, SP_BF16, ABL>), dim3(256), dim3(768), 0, s, g);
+    return check_launch("gemm_nt_rs_kernel");
+}
+
+// shape rules shared by the variants; the caller has validated pointers and dtypes
+bool nt_rs_ok(int M, int N, int K, int64_t lda, int64_t ldb, int64_t ldc, const void* A, const void* B, const void* C,
+              int out_dtype, int BN) {
+    return N % BN == 0 && K % 64 == 0 && K >= 64 && lda % 8 == 0 && ldb % 8 == 0 && lda >= K && ldb >= K && ldc >= N &&
+           ldc % (out_dtype == SP_F32 ? 4 : 8) == 0 && (((uintptr_t)A | (uintptr_t)B | (uintptr_t)C) & 15) == 0 &&
+           (int64_t)M * lda < ((int64_t)1 << 30) && (int64_t)N * ldb < ((int64_t)1 << 30) && M >= 1;
+}
+
+int gemm_nt_rs(const void* A, const void* B, void* C, int M, int N, int K, int64_t lda, int64_t ldb, int64_t ldc,
+               int out_dtype, int variant, hipStream_t s) {
+    switch (variant) {
+        case 0: return launch_nt_rs<192, 256, 2, 2>(A, B, C, M, N, K, lda, ldb, ldc, out_dtype, s);
+        case 1: return launch_nt_rs<128, 256, 2, 3>(A, B, C, M, N, K, lda, ldb, ldc, out_dtype, s);
+        case 2: return launch_nt_rs<192, 192, 4, 3>(A, B, C, M, N, K, lda, ldb, ldc, out_dtype, s);
+        case 3: return launch_nt_rs<256, 128, 4, 3>(A, B, C, M, N, K, lda, ldb, ldc, out_dtype, s);
+        case 10: return launch_nt_rs<192, 256, 2, 2, 1>(A, B, C, M, N, K, lda, ldb, ldc, out_dtype, s);
+        case 20: return launch_nt_rs<192, 256, 2, 2, 2>(A, B, C, M, N, K, lda, ldb, ldc, out_dtype, s);
+        case 30: return launch_nt_rs<192, 256, 2, 2, 3>(A, B, C, M, N, K, lda, ldb, ldc, out_dtype, s);
+        case 11: return launch_nt_rs<128, 256, 2, 3, 1>(A, B, C, M, N, K, lda, ldb, ldc, out_dtype, s);
+        case 21: return launch_nt_rs<128, 256, 2, 3, 2>(A, B, C, M, N, K, lda, ldb, ldc, out_dtype, s);
+        case 31: return launch_nt_rs<128, 256, 2, 3, 3>(A, B, C, M, N, K, lda, ldb, ldc, out_dtype, s);
+        default: return fail(SP_EINVAL, "gemm_nt_rs: variant %d", variant);
+    }
+}
+
+
+// -----------------------------------------------------------------------------------------------------
+//   TN:  P[z][i][j] = sum_{k in range z} X[k][i] * G[k][j]    (both operands stored k-major, i.e. row-
+//        contiguous in i / j: the weight gradients dW = LN(x)^T gU of the SRU layers and g^T x of the
+//        classifier, K = T'*B rows split into S ranges whose f32 partial products go to slabs)
+// Same roles and ring as the NT kernel; what differs is the operand path:
+//   * a stage holds 64 k-rows of a 256-column X panel and a 256-column G panel (512-byte rows); an LDS-DMA
+//     instruction moves two whole rows.  The loaders use BUFFER loads whose descriptor ends after the last
+//     valid k-row: rows past K (the last, partial K step) read as zeros, so no tail pass is needed;
+//   * the MFMA wants 8 consecutive k per lane, the rows hold consecutive i / j: fragments are read with
+//     ds_read_b64_tr_b16, which hands each lane one COLUMN of a 4 (k) x 16 (i) block.  A 32-lane half reads
+//     rows k..k+3 and k+8..k+11 of one 32-byte column group; 32-byte group c of row k is stored at group
+//     c ^ ((k & 3) | ((k >> 3) & 1) << 2), which spreads those 8 rows over the 8 groups of a 256-byte
+//     bank row: conflict-free (again applied on the DMA's source address).
+struct TnArgs {
+    const __hip_bfloat16* X; const __hip_bfloat16* G; float* P;
+    int Mi, Nj, K, ldx, ldg;
+    int64_t ldp, slab;                // row pitch and slab stride of P, in floats
+    int nti, ntj, S, steps_per;       // tiles, splits, K steps (of 64) per split
+};
+
+typedef short rs_s16x4 __attribute__((ext_vector_type(4)));
+
+template <int ABL = 0>
+__global__ __launch_bounds__(768, 3) void gemm_tn_rs_kernel(TnArgs g) {
+    constexpr int BI = 256, BJ = 256, NST = 2;
+    constexpr int MB = 8, NB = 4;                 // wave tile 128 (i) x 64 (j), waves 2 (i) x 4 (j)
+    constexpr int PART = 64 * 512, STAGE = 2 * PART;
+    constexpr int PER = 16;                       // DMA instructions per loader wave and stage
+    __shared__ __attribute__((aligned(1024))) unsigned char smem[NST * STAGE];
+
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    // items = (split z, tile): an XCD takes a contiguous run of the z-major list, so its workgroups share
+    // the X and G panels of (mostly) one K range in their L2
+    const int ntiles = g.nti * g.ntj, nitems = ntiles * g.S;
+    const int per_xcd = (nitems + 7) / 8, nslots = gridDim.x >> 3;
+    const int x_lo = (blockIdx.x & 7) * per_xcd, x_hi = min(x_lo + per_xcd, nitems);
+    const int first = x_lo + (blockIdx.x >> 3);
+    if (first >= x_hi) return;
+    const int count = (x_hi - first + nslots - 1) / nslots;
+    const int nsteps_all = (g.K + 63) / 64;
+    auto item_steps = [&](int item) {
+        const int z = item / ntiles;
+        return max(min(nsteps_all - z * g.steps_per, g.steps_per), 0);
+    };
+    int total = 0;
+    for (int c = 0; c < count; ++c) total += item_steps(first + c * nslots);
+
+    if (wave >= 8) {
+        // ------------------------------------------------------------------ loader
+        const int lw = wave - 8;
+        const auto rx = __builtin_amdgcn_make_buffer_rsrc((void*)g.X, 0, (int)((int64_t)g.K * g.ldx * 2), 0x00020000);
+        const auto rg = __builtin_amdgcn_make_buffer_rsrc((void*)g.G, 0, (int)((int64_t)g.K * g.ldg * 2), 0x00020000);
+        int vx[8], vg[8];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const int k = 2 * (lw + 4 * i) + (lane >> 5);          // row within the stage (both parts)
+            const int sk = (k & 3) | (((k >> 3) & 1) << 2);
+            const int c = (lane & 31) ^ (sk << 1);
+            vx[i] = k * g.ldx * 2 + c * 16;
+            vg[i] = k * g.ldg * 2 + c * 16;
+        }
+        int litem = first, lstep = 0, lsteps = item_steps(first), sx = 0, sg = 0;
+        auto set_item = [&](int item) {
+            const int z = item / ntiles, t = item % ntiles;
+            const int k0 = z * g.steps_per * 64;
+            sx = (k0 * g.ldx + (t % g.nti) * BI) * 2;
+            sg = (k0 * g.ldg + (t / g.nti) * BJ) * 2;
+        };
+        set_item(first);
+        auto issue = [&](int stage) {
+            if (ABL == 2) return;
+            unsigned char* st = smem + stage * STAGE + lw * 1024;
+#pragma unroll
+            for (int i = 0; i < 8; ++i)
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rx, (rs_lptr_t)(st + i * 4096), 16, vx[i], sx, 0, 0);
+#pragma unroll
+            for (int i = 0; i < 8; ++i)
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rg, (rs_lptr_t)(st + PART + i * 4096), 16, vg[i], sg, 0, 0);
+            sx += 64 * g.ldx * 2;
+            sg += 64 * g.ldg * 2;
+            if (++lstep == lsteps) {
+                lstep = 0;
+                litem += nslots;
+                if (litem < x_hi) { set_item(litem); lsteps = item_steps(litem); }
+                else lsteps = 1 << 30;      // past the last item: rows beyond the buffers read as zeros
+            }
+        };
+#pragma unroll
+        for (int s0 = 0; s0 < NST - 1; ++s0) issue(s0);
+        int fill = NST - 1;
+        for (int step = 0; step < total; ++step) {
+            asm volatile("s_waitcnt vmcnt(%0)" ::"n"((NST - 2) * PER) : "memory");
+            __builtin_amdgcn_s_barrier();
+            asm volatile("" ::: "memory");
+            issue(fill);
+            fill = fill + 1 == NST ? 0 : fill + 1;
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        return;
+    }
+
+    // ---------------------------------------------------------------------- compute
+    const int wi = wave >> 2, wj = wave & 3;
+    const int li = lane & 15, q = lane >> 4, qq = li >> 2, p = li & 3;
+    // transposed-read address of this lane inside a [64 k][256] part: row 8 q + qq (+ 32 kk, + 4 for the second
+    // half of the fragment), 32-byte group (block) ^ sk, byte (p >> 1) * 16 + (p & 1) * 8 inside the group
+    const int sk = qq | ((q & 1) << 2);
+    const int rowoff = (8 * q + qq) * 512 + (p >> 1) * 16 + (p & 1) * 8;
+    const uint32_t lds0 = (uint32_t)(uintptr_t)(rs_lptr_t)smem;
+    uint32_t ax[MB], ag[NB];
+#pragma unroll
+    for (int a = 0; a < MB; ++a) ax[a] = lds0 + rowoff + ((((wi * 8 + a) & 15) ^ sk) << 5);
+#pragma unroll
+    for (int b = 0; b < NB; ++b) ag[b] = lds0 + PART + rowoff + ((((wj * 4 + b) & 15) ^ sk) << 5);
+
+    rs_f32x4 acc[MB][NB];
+#pragma unroll
+    for (int a = 0; a < MB; ++a)
+#pragma unroll
+        for (int b = 0; b < NB; ++b) acc[a][b] = rs_f32x4{0.f, 0.f, 0.f, 0.f};
+
+    auto frag = [&](uint32_t addr) {
+        typedef __attribute__((address_space(3))) rs_s16x4* lp;
+        const rs_s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lp)(uintptr_t)addr);
+        const rs_s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lp)(uintptr_t)(addr + 4 * 512));
+        typedef short s16x8 __attribute__((ext_vector_type(8)));
+        const s16x8 v = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+        return __builtin_bit_cast(rs_bf16x8, v);
+    };
+
+    int citem = first, ck = 0, csteps = item_steps(first), stage = 0;
+    for (int step = 0; step < total; ++step) {
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+        const uint32_t so = stage * STAGE;
+#pragma unroll
+        for (int kk = 0; kk < (ABL == 1 ? 0 : 2); ++kk) {
+            const uint32_t ko = so + kk * 32 * 512;
+            rs_bf16x8 Pf[NB];
+#pragma unroll
+            for (int b = 0; b < NB; ++b) Pf[b] = frag(ag[b] + ko);
+#pragma unroll
+            for (int a = 0; a < MB; ++a) {
+                const rs_bf16x8 Q = frag(ax[a] + ko);
+#pragma unroll
+                for (int b = 0; b < NB; ++b) acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(Pf[b], Q, acc[a][b], 0, 0, 0);
+            }
+        }
+        asm volatile("" ::: "memory");
+        stage = stage + 1 == NST ? 0 : stage + 1;
+        if (++ck == csteps) {
+            // D[row = j][col = i]: lane = (i = li, q), register e -> j = 4 q + e
+            const int z = citem / ntiles, t = citem % ntiles;
+            const int i0 = (t % g.nti) * BI + wi * 128, j0 = (t / g.nti) * BJ + wj * 64;
+            float* Pz = g.P + (int64_t)z * g.slab;
+#pragma unroll
+            for (int a = 0; a < MB; ++a) {
+                float* crow = Pz + (int64_t)(i0 + a * 16 + li) * g.ldp + j0 + 4 * q;
+#pragma unroll
+                for (int b = 0; b < NB; ++b) {
+                    if (ABL != 3) *reinterpret_cast<rs_f32x4*>(crow + b * 16) = acc[a][b];
+                    acc[a][b] = rs_f32x4{0.f, 0.f, 0.f, 0.f};
+                }
+            }
+            ck = 0;
+            citem += nslots;
+            csteps = citem < x_hi ? item_steps(citem) : (1 << 30);
+        }
+    }
+}
+
+bool tn_rs_ok(int Mi, int Nj, int K, int64_t ldx, int64_t ldg, const void* X, const void* G, const void* P) {
+    return Mi % 256 == 0 && Nj % 256 == 0 && K >= 64 && ldx % 8 == 0 && ldg % 8 == 0 && ldx >= Mi && ldg >= Nj &&
+           (((uintptr_t)X | (uintptr_t)G | (uintptr_t)P) & 15) == 0 && (int64_t)K * ldx < ((int64_t)1 << 30) &&
+           (int64_t)K * ldg < ((int64_t)1 << 30);
+}
+
+// S = number of K ranges: the smallest that gives every CU an item (at most 64, at least 8 K steps each)
+int tn_rs_splits(int Mi, int Nj, int K) {
+    const int tiles = (Mi / 256) * (Nj / 256), nsteps = (K + 63) / 64;
+    int S = 256 / tiles;
+    if (S < 1) S = 1;
+    if (S > 64) S = 64;
+    while (S > 1 && (nsteps / S < 8 || (S - 1) * ((nsteps + S - 1) / S) >= nsteps)) --S;   // no empty range
+    return S;
+}
+
+int gemm_tn_rs(const void* X, const void* G, float* P, int Mi, int Nj, int K, int64_t ldx, int64_t ldg, int64_t ldp,
+               int64_t slab_stride, int S, int variant, hipStream_t s) {
+    TnArgs g;
+    g.X = (const __hip_bfloat16*)X; g.G = (const __hip_bfloat16*)G; g.P = P;
+    g.Mi = Mi; g.Nj = Nj; g.K = K; g.ldx = (int)ldx; g.ldg = (int)ldg;
+    g.ldp = ldp; g.slab = slab_stride;
+    g.nti = Mi / 256; g.ntj = Nj / 256; g.S = S;
+    g.steps_per = ((K + 63) / 64 + S - 1) / S;
+    switch (variant) {
+        case 0: hipLaunchKernelGGL((gemm_tn_rs_kernel<0>), dim3(256), dim3(768), 0, s, g); break;
+        case 10: hipLaunchKernelGGL((gemm_tn_rs_kernel<1>), dim3(256), dim3(768), 0, s, g); break;
+        case 20: hipLaunchKernelGGL((gemm_tn_rs_kernel<2>), dim3(256), dim3(768), 0, s, g); break;
+        case 30: hipLaunchKernelGGL((gemm_tn_rs_kernel<3>), dim3(256), dim3(768), 0, s, g); break;
+        default: return fail(SP_EINVAL, "gemm_tn_rs: variant %d", variant);
+    }
+    return check_launch("gemm_tn_rs_kernel");
+}
+
+}  // namespace sp
+
+extern "C" int sp_lab_gemm_tn(const void* X, const void* G, void* P, int Mi, int Nj, int K, int64_t ldx, int64_t ldg,
+                              int S, int variant, void* stream) {
+    using namespace sp;
+    SP_CHECK_ARG(tn_rs_ok(Mi, Nj, K, ldx, ldg, X, G, P) && S >= 1 && S <= 64, "sp_lab_gemm_tn: shape not supported");
+    return gemm_tn_rs(X, G, (float*)P, Mi, Nj, K, ldx, ldg, Nj, (int64_t)Mi * Nj, S, variant, reinterpret_cast<hipStream_t>(stream));
+}
+
+namespace sp {
+}  // namespace sp
+
+extern "C" void sp_lab_set(int key, int value) {
+    if (key >= 0 && key < 8) sp::g_lab[key] = value;
+}
+
+// development entry point (tools/gemm_lab.py): one named variant of the role-split kernels
+extern "C" int sp_lab_gemm_nt(const void* A, const void* B, void* C, int M, int N, int K, int64_t lda, int64_t ldb,
+                              int64_t ldc, int out_dtype, int variant, void* stream) {
+    using namespace sp;
+    static const int bn[] = {256, 256, 192, 128};
+    SP_CHECK_ARG(variant >= 0 && variant % 10 < 4, "sp_lab_gemm_nt: variant %d", variant);
+    SP_CHECK_ARG(nt_rs_ok(M, N, K, lda, ldb, ldc, A, B, C, out_dtype, bn[variant % 10]), "sp_lab_gemm_nt: shape not supported");
+    return gemm_nt_rs(A, B, C, M, N, K, lda, ldb, ldc, out_dtype, variant, reinterpret_cast<hipStream_t>(stream));
+}

@@ -132,7 +132,7 @@ def _workspace(key, nbytes, device):
 
 
 def ctc_fwd_bwd(logits, labels, input_lengths, label_lengths, blank=0, max_label_len=None,
-                time_major=False, grad_scale=1.0, want_grad=True, grad_dtype=torch.float32):
+                time_major=False, grad_scale=1.0, want_grad=True, grad_dtype=torch.float32, grad_out=None):
     """logits [B,T,V] (or [T,B,V] when time_major) f32 -> (loss[1], nll[B], grad like logits).
 
     loss = mean_b nll_b / max(L_b, 1) of log_softmax(logits); grad = grad_scale * dloss/dlogits, stored as
@@ -165,7 +165,12 @@ def ctc_fwd_bwd(logits, labels, input_lengths, label_lengths, blank=0, max_label
         max_label_len = min(int(labels.shape[1]), 1023)
     nll = torch.empty(B, dtype=torch.float32, device=dev)
     loss = torch.empty(1, dtype=torch.float32, device=dev)
-    grad = torch.empty_strided(logits.shape, logits.stride(), dtype=grad_dtype, device=dev) if want_grad else None
+    if grad_out is not None:      # caller-owned gradient buffer, same strides (in elements) as the logits
+        if grad_out.stride() != logits.stride() or grad_out.shape != logits.shape or grad_out.dtype != grad_dtype:
+            raise ValueError("grad_out must match the logits' shape and strides and have grad_dtype")
+        grad = grad_out
+    else:
+        grad = torch.empty_strided(logits.shape, logits.stride(), dtype=grad_dtype, device=dev) if want_grad else None
     nbytes = lib().sp_ctc_workspace_bytes(T, B, V, max_label_len)
     ws = _workspace((dev.index, "ctc"), nbytes, dev)
     with torch.cuda.device(dev):
@@ -359,23 +364,6 @@ def gemm(a, b, out=None, out_dtype=None, accumulate=False, split_k=1):
     return out
 
 
-def gemm_nt(a, b, out=None):
-    """a [M,K] @ b[N,K]^T -> [M,N] on the bf16 K-contiguous kernels directly (sp_gemm_nt_bf16)."""
-    _need_cuda(a, "a")
-    M, K = a.shape
-    N = b.shape[0]
-    if a.dtype != torch.bfloat16 or b.dtype != torch.bfloat16 or b.shape[1] != K:
-        raise ValueError("gemm_nt: bf16 operands [M,K] and [N,K] expected")
-    if a.stride(1) != 1 or b.stride(1) != 1:
-        raise ValueError("gemm_nt: operands must be K-contiguous")
-    if out is None:
-        out = torch.empty((M, N), dtype=torch.bfloat16, device=a.device)
-    with torch.cuda.device(a.device):
-        check(lib().sp_gemm_nt_bf16(ptr(a), ptr(b), ptr(out), M, N, K, a.stride(0), b.stride(0), out.stride(0),
-                                    stream_ptr()), "sp_gemm_nt_bf16")
-    return out
-
-
 def sum_slabs(partials, out=None, accumulate=False, scale=None):
     """partials [S, ...] f32 -> sum over S (times the device scalar `scale`), written or added to `out`."""
     S = partials.shape[0]
@@ -461,7 +449,7 @@ def sru_pack_w(weight, d, k, C, dtype):
 
 def sru_pack_wt(weight, d, k, C, dtype, pad=0, both=False):
     """state_dict weight f32 [n_in, 2*d*k] -> WkT [k*2*d, n_in] in dtype (columns f*C + c): sru_pack_w's
-    result transposed, the K-contiguous B operand of gemm_nt; pad: extra elements per row of the buffer.
+    result transposed, the K-contiguous B operand of the projection GEMM; pad: extra elements per row of the buffer.
     both=True: returns (WkT, Wk), the second being sru_pack_w's layout written in the same pass."""
     n_in = weight.shape[0]
     out = torch.empty((k * 2 * d, n_in + pad), dtype=dtype, device=weight.device)[:, :n_in]
@@ -485,35 +473,60 @@ def sru_unpack_dw(partials, n_in, d, k, C, out=None):
     return out
 
 
-def _splitk_dw(xn, gU2, S):
+def _splitk_dw(xn, gU2):
     """f32 partials [S, n_in, N] of xn^T gU: the output has only n_in/256 * N/256 = 48 tiles for 256
     CUs at the reference's sizes, so K (= T*B) is split S ways into slabs (no atomics; the slabs are
-    summed by sp_sru_unpack_dw / sp_sum_slabs_f32)."""
+    summed by sp_sru_unpack_dw / sp_sum_slabs_f32).  S is the library's choice for the shape."""
+    S = lib().sp_gemm_tn_splits(xn.shape[1], gU2.shape[1], xn.shape[0], _lib.dtype_code(xn))
     out = gemm(xn.t(), gU2.t(), out_dtype=torch.float32, split_k=S)
     return out if S > 1 else out.unsqueeze(0)
 
 
-def _dw_splits(M):
-    return 8 if M >= 8192 else (4 if M >= 2048 else 1)
+_VPAD = 256     # the fast GEMM kernels work on whole 256-column tiles
+
+
+def _classifier_pack(weight, dtype, M):
+    """The classifier weight [V, n] in the activation dtype, rows zero-padded to whole 256-column tiles when
+    the problem is big enough for the persistent kernels (logits and their gradient are then [M, Vp] buffers of
+    which the CTC kernels see the first V columns)."""
+    V, n = weight.shape
+    if dtype != torch.bfloat16 or M < 4096 or n % 256 or V % _VPAD == 0:
+        return weight.detach().to(dtype), V
+    Vp = (V + _VPAD - 1) // _VPAD * _VPAD
+    wb = torch.zeros((Vp, n), dtype=dtype, device=weight.device)
+    wb[:V].copy_(weight.detach())
+    return wb, Vp
 
 
 def _classifier_logits(x2d, weight):
-    """(f32 logits [M, V] straight from the GEMM's f32 accumulators, the weight in the activation dtype)."""
-    wb = weight.detach().to(x2d.dtype)
-    return gemm(x2d, wb, out_dtype=torch.float32), wb
+    """(f32 logits [M, V] straight from the GEMM's f32 accumulators -- a view of an [M, Vp] buffer when the weight
+    was padded --, the (padded) weight in the activation dtype)."""
+    wb, Vp = _classifier_pack(weight, x2d.dtype, x2d.shape[0])
+    return gemm(x2d, wb, out_dtype=torch.float32)[:, :weight.shape[0]], wb
+
+
+def _classifier_dx(gb, wb, scale=None):
+    """gb [M, Vp] (pad columns zero) times wb [Vp, n]; with a padded weight as an NT product on wb^T."""
+    w = wb if scale is None else (wb.float() * scale).to(wb.dtype)
+    if wb.shape[0] % _VPAD == 0 and gb.shape[0] >= 4096 and wb.dtype == torch.bfloat16:
+        return gemm(gb, w.t().contiguous())
+    return gemm(gb, w.t())
 
 
 def _classifier_dw(gb, x2d, weight, scale=None):
     """Weight gradient g^T x of the classifier -- a [V, n] output with K = T'*B, split over the rows into
     slabs that are summed (times the incoming loss gradient) straight into the parameter's gradient
-    buffer when the step owns one (GradSink); returns None then, else the gradient tensor."""
-    P = _splitk_dw(gb, x2d, _dw_splits(x2d.shape[0]))
+    buffer when the step owns one (GradSink); returns None then, else the gradient tensor.  gb may carry
+    zero pad columns (rows of the product beyond V, which are dropped)."""
+    V = weight.shape[0]
+    P = _splitk_dw(gb, x2d)[:, :V]
     sink = _sink
-    if sink is not None and sink.ok(weight) and P[0].numel() % 4 == 0:
+    vec = P[0].numel() % 4 == 0
+    if vec and sink is not None and sink.ok(weight):
         sum_slabs(P, weight.grad, True, scale)
         sink.ready(weight)
         return None
-    if P[0].numel() % 4 == 0:
+    if vec:
         return sum_slabs(P, None, False, scale).to(weight.dtype)
     gw = P.sum(0)
     return (gw * scale if scale is not None else gw).to(weight.dtype)
@@ -534,9 +547,14 @@ class _ClassifierFn(torch.autograd.Function):
     @staticmethod
     def backward(ctx, g):
         x2d, wb = ctx.saved_tensors
-        gb = g.to(x2d.dtype).contiguous()
-        gx = gemm(gb, wb.t())
-        return gx, _classifier_dw(gb, x2d, ctx.weight)
+        V, Vp = ctx.weight.shape[0], wb.shape[0]
+        if Vp != V:         # pad columns zero: they meet the padded weight's zero rows
+            gb = torch.empty((g.shape[0], Vp), dtype=x2d.dtype, device=g.device)
+            gb[:, V:].zero_()
+            gb[:, :V].copy_(g)
+        else:
+            gb = g.to(x2d.dtype).contiguous()
+        return _classifier_dx(gb, wb), _classifier_dw(gb, x2d, ctx.weight)
 
 
 class _HeadCTCFn(torch.autograd.Function):
@@ -549,22 +567,27 @@ class _HeadCTCFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x_tm, weight, labels, label_lengths, blank, max_label_len):
         T, B, n = x_tm.shape
+        V = weight.shape[0]
         x2d = x_tm.reshape(T * B, n)
-        logits, wb = _classifier_logits(x2d, weight)
-        logits = logits.view(T, B, -1)
+        logits, wb = _classifier_logits(x2d, weight)            # [T*B, V] view, row pitch Vp
+        Vp = wb.shape[0]
         ctx.weight = weight
         il = torch.full((B,), T, dtype=torch.int32, device=x_tm.device)        # train.py:72-74: all T' frames
-        loss, _, grad = ctc_fwd_bwd(logits, labels, il, label_lengths, blank, max_label_len, True, 1.0, True,
-                                    x2d.dtype)            # the gradient leaves the kernel in the GEMMs' dtype
-        ctx.save_for_backward(x2d, wb, grad.view(T * B, -1))
+        gbuf = torch.empty((T * B, Vp), dtype=x2d.dtype, device=x2d.device)    # the gradient leaves the kernel in
+        if Vp != V:                                                            # the GEMMs' dtype, pad columns zero
+            gbuf[:, V:].zero_()
+        loss, _, _ = ctc_fwd_bwd(logits.as_strided((T, B, V), (B * Vp, Vp, 1)), labels, il, label_lengths, blank,
+                                 max_label_len, True, 1.0, True, x2d.dtype,
+                                 grad_out=gbuf.as_strided((T, B, V), (B * Vp, Vp, 1)))
+        ctx.save_for_backward(x2d, wb, gbuf)
         ctx.shape = (T, B, n)
         return loss[0]
 
     @staticmethod
     def backward(ctx, g):
         x2d, wb, gb = ctx.saved_tensors
-        gx = gemm(gb, (wb.float() * g).to(wb.dtype).t())
-        return gx.view(ctx.shape), _classifier_dw(gb, x2d, ctx.weight, g), None, None, None, None
+        return (_classifier_dx(gb, wb, g).view(ctx.shape), _classifier_dw(gb, x2d, ctx.weight, g),
+                None, None, None, None)
 
 
 def classifier_ctc_loss(x_tm, weight, labels, label_lengths, blank=0, max_label_len=None):
@@ -641,7 +664,7 @@ class _SRULayerFn(torch.autograd.Function):
                                         wc.grad.view(-1) if direct else None, bias.grad.view(-1) if direct else None)
         gU2 = gU.view(T * B, -1)
         M = T * B
-        gw = sru_unpack_dw(_splitk_dw(xn, gU2, 4 if M >= 4096 else 1), n_in, d, k, C, weight.grad if direct else None)
+        gw = sru_unpack_dw(_splitk_dw(xn, gU2), n_in, d, k, C, weight.grad if direct else None)
         gxn = gemm(gU2, wk)
         gres = gxres.view(T * B, n_in) if k == 3 else None
         ln_direct = direct and C == 1   # layer 0's vectors are stored in the reference's c*F + f order

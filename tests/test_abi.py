@@ -43,18 +43,6 @@ def test_version_and_error_string():
     assert rc == -1 and b"exceeds" in h.sp_last_error()
     rc = h.sp_ctc_fwd_bwd(None, 0, 0, None, 0, None, None, 10, 2, 29, 0, 4, 1.0, None, None, 1, 7, None, 0, None)
     assert rc == -1 and b"grad_dtype" in h.sp_last_error()
-    # the hand-written GEMM: shape, pitch and alignment rules (no launch happens on a refusal)
-    rc = h.sp_gemm_nt_bf16(16, 16, 16, 256, 100, 64, 64, 64, 128, None)
-    assert rc == -1 and b"multiple of 128" in h.sp_last_error()
-    rc = h.sp_gemm_nt_bf16(16, 16, 16, 256, 128, 48, 64, 64, 128, None)
-    assert rc == -1 and b"multiple of 128" in h.sp_last_error()          # K % 32
-    rc = h.sp_gemm_nt_bf16(16, 16, 16, 256, 128, 64, 60, 64, 128, None)
-    assert rc == -1 and b"leading dimensions" in h.sp_last_error()
-    rc = h.sp_gemm_nt_bf16(None, 16, 16, 256, 128, 64, 64, 64, 128, None)
-    assert rc == -1 and b"null pointer" in h.sp_last_error()
-    rc = h.sp_gemm_nt_bf16(8, 16, 16, 256, 128, 64, 64, 64, 128, None)
-    assert rc == -1 and b"aligned" in h.sp_last_error()
-    assert h.sp_gemm_nt_bf16(None, None, None, 0, 128, 64, 64, 64, 128, None) == 0      # M = 0: nothing to do
     # the general GEMM: strides, dtypes, slabs
     rc = h.sp_gemm(16, 16, 16, 8, 8, 8, 16, 2, 8, 1, 8, 2, 2, 0, 1, 0, None)
     assert rc == -1 and b"contiguous along k" in h.sp_last_error()
@@ -67,6 +55,8 @@ def test_version_and_error_string():
     rc = h.sp_gemm(16, 16, 16, 8, 8, 8, 8, 1, 8, 1, 8, 5, 0, 0, 1, 0, None)
     assert rc == -1 and b"in_dtype" in h.sp_last_error()
     assert h.sp_gemm(None, None, None, 0, 8, 8, 8, 1, 8, 1, 8, 2, 2, 0, 1, 0, None) == 0
+    assert h.sp_gemm_tn_splits(1024, 3072, 24032, 2) == 5 and h.sp_gemm_tn_splits(1024, 1024, 24032, 2) == 16
+    assert h.sp_gemm_tn_splits(1024, 3072, 24032, 0) == 8 and h.sp_gemm_tn_splits(100, 100, 100, 2) == 1
     rc = h.sp_sum_slabs_f32(16, 2, 6, 8, 16, 0, None, None)
     assert rc == -1 and b"multiples of 4" in h.sp_last_error()
     rc = h.sp_sru_pack_wt(16, 96, 64, 3, 1, 2, 16, 96, None, None)

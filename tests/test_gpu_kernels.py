@@ -662,20 +662,21 @@ def test_conv_fused_bn_sums_are_reproducible(cuda):
                                    (24032, 3072, 1024), (12345, 2048, 192), (49155, 256, 64),
                                    (100, 65536, 64), (200001, 256, 128), (24032, 4096, 1280)])
 def test_gemm_nt_bf16(cuda, M, N, K):
-    """sp_gemm_nt_bf16 against an f32 matmul of the same bf16 operands (ragged M, strided rows)."""
+    """sp_gemm on K-contiguous bf16 operands (the persistent role-split kernel from 64 tiles up, the general
+    kernel below) against an f32 matmul of the same operands (ragged M, strided rows)."""
     from speech_amd import ops
     g = torch.Generator().manual_seed(M + N + K)
     a = torch.randn(M, K, generator=g).bfloat16().to(cuda)
     b = (torch.randn(N, K, generator=g) * 0.1).bfloat16().to(cuda)
-    out = ops.gemm_nt(a, b)
+    out = ops.gemm(a, b)
     ref = a.float() @ b.float().t()
     err = float((out.float() - ref).abs().max())
     assert err <= 1e-2 * float(ref.abs().max()) + 1e-3          # bf16 output rounding
     if M >= 300:   # operands that are row slices of wider buffers
         aw = torch.randn(M, K + 64, generator=g).bfloat16().to(cuda)
-        out2 = ops.gemm_nt(aw[:, 32:32 + K].contiguous(), b)
+        out2 = ops.gemm(aw[:, 32:32 + K].contiguous(), b)
         out3 = torch.empty(M, N + 8, dtype=torch.bfloat16, device=cuda)
-        ops.gemm_nt(aw[:, 32:32 + K].contiguous(), b, out=out3[:, :N])
+        ops.gemm(aw[:, 32:32 + K].contiguous(), b, out=out3[:, :N])
         assert torch.equal(out2, out3[:, :N])
 
 
@@ -741,3 +742,27 @@ def test_gemm_general_unaligned_and_strided(cuda):
     ap = torch.zeros(M, 40, device=cuda).bfloat16()
     ap[:, :K] = a
     assert torch.equal(ops.gemm(ap[:, :K], b, out_dtype=torch.float32), out)
+
+
+@pytest.mark.parametrize("Mi,Nj,K", [(1024, 3072, 24032), (1280, 4096, 24032), (1024, 1024, 24032), (256, 1024, 24032),
+                                     (512, 768, 4100), (256, 256, 8191)])
+def test_gemm_tn_splitk_bf16(cuda, Mi, Nj, K):
+    """The weight-gradient form X^T G (both operands row-contiguous, K = T'*B rows, f32 split-K slabs) on the
+    persistent TN kernel: transposed LDS reads, a ragged last K step (rows past K read as zeros), padded
+    operand pitches; against an f64 product of the same bf16 inputs."""
+    from speech_amd import _lib, ops
+    g = torch.Generator().manual_seed(Mi + Nj + K)
+    xb = torch.zeros(K, Mi + 64, dtype=torch.bfloat16, device=cuda)
+    xb[:, :Mi] = torch.randn(K, Mi, generator=g).bfloat16().to(cuda)
+    x = xb[:, :Mi]
+    gu = (torch.randn(K, Nj, generator=g) * 0.1).bfloat16().to(cuda)
+    S = _lib.lib().sp_gemm_tn_splits(Mi, Nj, K, _lib.SP_BF16)
+    assert 1 <= S <= 64
+    P = ops.gemm(x.t(), gu.t(), out_dtype=torch.float32, split_k=S)
+    P = P if S > 1 else P.unsqueeze(0)
+    ref = x.double().t() @ gu.double()
+    assert float((P.double().sum(0) - ref).abs().max()) <= 2e-5 * float(ref.abs().max())
+    # slabs into a wider buffer: pitch and slab stride are honoured
+    wide = torch.full((S, Mi, Nj + 16), 7.0, device=cuda)
+    ops.gemm(x.t(), gu.t(), out=wide[:, :, :Nj] if S > 1 else wide[0, :, :Nj], out_dtype=torch.float32, split_k=S)
+    assert torch.equal(wide[:, :, :Nj], P) and float((wide[:, :, Nj:] - 7.0).abs().max()) == 0

@@ -18,7 +18,7 @@ oU = torch.empty(M, 3072, device=dev, dtype=torch.bfloat16); oX = torch.empty(M,
 fwd_only = len(sys.argv) > 1 and sys.argv[1] == "fwd"     # only the own forward GEMM (bench.py's traffic figure)
 for _ in range(3):
     if fwd_only:
-        ops.gemm_nt(xn, wkT, out=oU)
+        ops.gemm(xn, wkT, out=oU)
         continue
-    torch.mm(xn, wk, out=oU); ops.gemm_nt(xn, wkT, out=oU); torch.mm(gU, wk.t(), out=oX); ops.gemm_nt(gU, wk, out=oX)
+    torch.mm(xn, wk, out=oU); ops.gemm(xn, wkT, out=oU); torch.mm(gU, wk.t(), out=oX); ops.gemm(gU, wk, out=oX)
 torch.cuda.synchronize()

@@ -33,13 +33,11 @@ typedef uint32_t rs_u32x4 __attribute__((ext_vector_type(4)));
 typedef __attribute__((address_space(1))) const void* rs_gptr_t;
 typedef __attribute__((address_space(3))) void* rs_lptr_t;
 
-int g_lab[8] = {0, 0, 0, 0, 0, 0, 0, 0};     // development knobs (sp_lab_set): [0] gcols override, [1] non-temporal C stores
-
 struct RsArgs {
     const __hip_bfloat16* A; const __hip_bfloat16* B; void* C;
     int M, N, K, lda, ldb;
     int64_t ldc;
-    int ntn, ntm, gcols, nts;
+    int ntn, ntm, gcols;
 };
 
 // XCD-aware tile ownership.  The eight XCDs (workgroup b runs on XCD b % 8) form a gcols x (8 / gcols)
@@ -64,18 +62,24 @@ struct RsTiles {
     __device__ __forceinline__ int tile_n(int i) const { return col0 + i % cols_per; }
 };
 
-// BM x BN tile, WMW x WNW compute waves (= 8), NST ring stages of K = 64, OUT = SP_BF16 or SP_F32
-template <int BM, int BN, int WMW, int NST, int OUT, int ABL = 0>
+// BM x BN tile, WMW x WNW compute waves (= 8), OUT = SP_BF16 or SP_F32.  The A rows and the B rows of a K = 64
+// step live in two separate rings: B -- the weight panels, L2-resident, short latency -- two stages deep, A --
+// activations or their gradients, streamed from beyond the L2 -- NSTA = 2 or 3 stages deep.  Every loader wave
+// issues its share of B for the next step first and then its share of A for the step after (NSTA = 3); its
+// counted wait before the barrier leaves exactly that A share in flight (a wave's vector-memory operations retire
+// in issue order, so everything older has landed).  All four loaders share both operands: the far operand's
+// requests leave in a quarter of the time one wave would need to issue them.
+template <int BM, int BN, int WMW, int NSTA, int OUT>
 __global__ __launch_bounds__(768, 3) void gemm_nt_rs_kernel(RsArgs g) {
-    constexpr int WNW = 8 / WMW;
+    constexpr int WNW = 8 / WMW, NSTB = 2;
     constexpr int TM = BM / WMW, TN = BN / WNW;          // wave tile
     constexpr int MB = TM / 16, NB = TN / 16;
-    constexpr int ROWB = 128, STAGE = (BM + BN) * ROWB;
-    constexpr int GA = BM / 8, G = (BM + BN) / 8;        // 8-row DMA groups per stage
-    constexpr int PER = G / 4;                           // ... per loader wave
-    static_assert(G % 4 == 0 && GA % 4 == 0 && NB % 2 == 0 && TM % 16 == 0 && TN % 16 == 0, "tile shape");
-    static_assert(NST * STAGE <= 160 * 1024, "LDS");
-    __shared__ __attribute__((aligned(1024))) unsigned char smem[NST * STAGE];
+    constexpr int ROWB = 128, STA = BM * ROWB, STB = BN * ROWB, BOFF = NSTA * STA;
+    constexpr int PA = BM / 32, PB = BN / 32;            // 8-row DMA groups per stage and loader wave
+    static_assert(BM % 32 == 0 && BN % 32 == 0 && NB % 2 == 0 && TM % 16 == 0 && TN % 16 == 0, "tile shape");
+    static_assert(NSTA == 2 || NSTA == 3, "A ring depth");
+    static_assert(NSTA * STA + NSTB * STB <= 160 * 1024, "LDS");
+    __shared__ __attribute__((aligned(1024))) unsigned char smem[NSTA * STA + NSTB * STB];
 
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -88,45 +92,62 @@ __global__ __launch_bounds__(768, 3) void gemm_nt_rs_kernel(RsArgs g) {
         // ------------------------------------------------------------------ loader
         const int lw = wave - 8;
         const int drow = lane >> 3;
-        const int lchunk = (lane & 7) ^ (((lw & 1) << 2) | (drow >> 1));
-        int a_off[GA / 4], b_off[(G - GA) / 4];
-        int ltile = tl.first, lk = 0;
-        auto set_tile = [&](int tile) {
-            const int m0 = tl.tile_m(tile) * BM, n0 = tl.tile_n(tile) * BN;
+        const int lchunk = (lane & 7) ^ (((lw & 1) << 2) | (drow >> 1));      // row = 8 (lw + 4 i) + drow
+        int a_off[PA], b_off[PB];
+        // two cursors over the flat (tile, k) sequence: A runs one step further ahead than B when NSTA = 3
+        int atile = tl.first, ak = 0, btile = tl.first, bk = 0;
+        auto set_a = [&](int tile) {
+            const int m0 = tl.tile_m(tile) * BM;
 #pragma unroll
-            for (int i = 0; i < GA / 4; ++i)     // rows past M are never stored: clamp their source
+            for (int i = 0; i < PA; ++i)     // rows past M are never stored: clamp their source
                 a_off[i] = min(m0 + 8 * (lw + 4 * i) + drow, g.M - 1) * g.lda + lchunk * 8;
-#pragma unroll
-            for (int i = 0; i < (G - GA) / 4; ++i)
-                b_off[i] = (n0 + 8 * (lw + 4 * i) + drow) * g.ldb + lchunk * 8;
         };
-        set_tile(ltile);
-        auto issue = [&](int stage) {
-            unsigned char* st = smem + stage * STAGE + lw * 1024;
-            if (ABL == 2) return;
-            const __hip_bfloat16* ap = g.A + lk * 64;
-            const __hip_bfloat16* bp = g.B + lk * 64;
+        auto set_b = [&](int tile) {
+            const int n0 = tl.tile_n(tile) * BN;
 #pragma unroll
-            for (int i = 0; i < GA / 4; ++i)
+            for (int i = 0; i < PB; ++i) b_off[i] = (n0 + 8 * (lw + 4 * i) + drow) * g.ldb + lchunk * 8;
+        };
+        set_a(atile);
+        set_b(btile);
+        auto issueA = [&](int stage) {
+            unsigned char* st = smem + stage * STA + lw * 1024;
+            const __hip_bfloat16* ap = g.A + ak * 64;
+#pragma unroll
+            for (int i = 0; i < PA; ++i)
                 __builtin_amdgcn_global_load_lds((rs_gptr_t)(ap + a_off[i]), (rs_lptr_t)(st + i * 4096), 16, 0, 0);
-#pragma unroll
-            for (int i = 0; i < (G - GA) / 4; ++i)
-                __builtin_amdgcn_global_load_lds((rs_gptr_t)(bp + b_off[i]), (rs_lptr_t)(st + BM * ROWB + i * 4096), 16, 0, 0);
-            if (++lk == nk) {
-                lk = 0;
-                ltile += tl.nslots;
-                if (ltile < tl.run1) set_tile(ltile);     // past the last tile: harmless re-loads keep vmcnt uniform
+            if (++ak == nk) {
+                ak = 0;
+                atile += tl.nslots;
+                if (atile < tl.run1) set_a(atile);     // past the last tile: harmless re-loads keep vmcnt uniform
             }
         };
+        auto issueB = [&](int stage) {
+            unsigned char* st = smem + BOFF + stage * STB + lw * 1024;
+            const __hip_bfloat16* bp = g.B + bk * 64;
 #pragma unroll
-        for (int s = 0; s < NST - 1; ++s) issue(s);
-        int fill = NST - 1;                  // stage the next issue goes to
+            for (int i = 0; i < PB; ++i)
+                __builtin_amdgcn_global_load_lds((rs_gptr_t)(bp + b_off[i]), (rs_lptr_t)(st + i * 4096), 16, 0, 0);
+            if (++bk == nk) {
+                bk = 0;
+                btile += tl.nslots;
+                if (btile < tl.run1) set_b(btile);
+            }
+        };
+        // prologue: A(0) [A(1)], B(0)
+        issueA(0);
+        if (NSTA == 3) issueA(1);
+        issueB(0);
+        int fa = NSTA - 1, fb = 1;           // stages the next issues go to
         for (int step = 0; step < total; ++step) {
-            asm volatile("s_waitcnt vmcnt(%0)" ::"n"((NST - 2) * PER) : "memory");    // this wave's share of `step` landed
-            __builtin_amdgcn_s_barrier();    // B_step: stage of `step` is complete, stage of step - 1 is free
+            // in flight may stay: nothing (NSTA = 2) or this wave's share of A(step + 1), issued after B(step)
+            if (step == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NSTA == 3 ? PA : 0) : "memory");
+            __builtin_amdgcn_s_barrier();    // B_step: the stages of `step` are complete, those of step - 1 free
             asm volatile("" ::: "memory");
-            issue(fill);                     // step + NST - 1
-            fill = fill + 1 == NST ? 0 : fill + 1;
+            issueB(fb);                      // B(step + 1)
+            issueA(fa);                      // A(step + NSTA - 1)
+            fb ^= 1;
+            fa = fa + 1 == NSTA ? 0 : fa + 1;
         }
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // nothing may land after the workgroup's LDS is released
         return;
@@ -137,7 +158,7 @@ __global__ __launch_bounds__(768, 3) void gemm_nt_rs_kernel(RsArgs g) {
     const int li = lane & 15, q = lane >> 4;
     const int swz = (li >> 1) & 7;
     const unsigned char* sa0 = smem + (wm * TM + li) * ROWB;
-    const unsigned char* sb0 = smem + BM * ROWB + (wn * TN + li) * ROWB;
+    const unsigned char* sb0 = smem + BOFF + (wn * TN + li) * ROWB;
     const int pc0 = ((0 + q) ^ swz) * 16, pc1 = ((4 + q) ^ swz) * 16;
 
     rs_f32x4 acc[MB][NB];
@@ -146,14 +167,14 @@ __global__ __launch_bounds__(768, 3) void gemm_nt_rs_kernel(RsArgs g) {
 #pragma unroll
         for (int b = 0; b < NB; ++b) acc[a][b] = rs_f32x4{0.f, 0.f, 0.f, 0.f};
 
-    int ctile = tl.first, ck = 0, stage = 0;
+    int ctile = tl.first, ck = 0, stageA = 0, stageB = 0;
     for (int step = 0; step < total; ++step) {
         __builtin_amdgcn_s_barrier();        // B_step
         asm volatile("" ::: "memory");
-        const unsigned char* sa = sa0 + stage * STAGE;
-        const unsigned char* sb = sb0 + stage * STAGE;
+        const unsigned char* sa = sa0 + stageA * STA;
+        const unsigned char* sb = sb0 + stageB * STB;
 #pragma unroll
-        for (int kk = 0; kk < (ABL == 1 ? 0 : 2); ++kk) {
+        for (int kk = 0; kk < 2; ++kk) {
             const int pc = kk ? pc1 : pc0;
             rs_bf16x8 P[NB];
 #pragma unroll
@@ -166,7 +187,8 @@ __global__ __launch_bounds__(768, 3) void gemm_nt_rs_kernel(RsArgs g) {
             }
         }
         asm volatile("" ::: "memory");
-        stage = stage + 1 == NST ? 0 : stage + 1;
+        stageA = stageA + 1 == NSTA ? 0 : stageA + 1;
+        stageB = stageB + 1 == NSTB ? 0 : stageB + 1;
         if (++ck == nk) {
             // D[row = n][col = m]: lane = (m = li, q), register e -> n = 4 q + e
             const int m0 = tl.tile_m(ctile) * BM + wm * TM, n0 = tl.tile_n(ctile) * BN + wn * TN;
@@ -175,31 +197,32 @@ __global__ __launch_bounds__(768, 3) void gemm_nt_rs_kernel(RsArgs g) {
                 const int m = m0 + a * 16 + li;
                 if constexpr (OUT == SP_F32) {
                     float* crow = reinterpret_cast<float*>(g.C) + (int64_t)m * g.ldc + n0 + 4 * q;
-                    if (m < g.M && ABL != 3) {
+                    if (m < g.M) {
 #pragma unroll
-                        for (int b = 0; b < NB; ++b) {
-                            if (g.nts) __builtin_nontemporal_store(acc[a][b], reinterpret_cast<rs_f32x4*>(crow + b * 16));
-                            else *reinterpret_cast<rs_f32x4*>(crow + b * 16) = acc[a][b];
-                        }
+                        for (int b = 0; b < NB; ++b) *reinterpret_cast<rs_f32x4*>(crow + b * 16) = acc[a][b];
                     }
                 } else {
-                    __hip_bfloat16* crow = reinterpret_cast<__hip_bfloat16*>(g.C) + (int64_t)m * g.ldc + n0 + (q & 1) * 16 + (q >> 1) * 8;
+                    auto pk = [](float lo, float hi) {
+                        return (uint32_t)__builtin_bit_cast(unsigned short, __float2bfloat16(lo)) |
+                               ((uint32_t)__builtin_bit_cast(unsigned short, __float2bfloat16(hi)) << 16);
+                    };
+                    // rows (16-lane groups) 1 and 3 of x trade places with rows 0 and 2 of y: every lane then holds 8
+                    // consecutive n: columns 16 b + (q & 1) * 16 + (q >> 1) * 8 of its row
+                    rs_u32x4 o[NB / 2];
 #pragma unroll
                     for (int b = 0; b < NB; b += 2) {
-                        auto pk = [](float lo, float hi) {
-                            return (uint32_t)__builtin_bit_cast(unsigned short, __float2bfloat16(lo)) |
-                                   ((uint32_t)__builtin_bit_cast(unsigned short, __float2bfloat16(hi)) << 16);
-                        };
                         const uint32_t x0 = pk(acc[a][b][0], acc[a][b][1]), x1 = pk(acc[a][b][2], acc[a][b][3]);
                         const uint32_t y0 = pk(acc[a][b + 1][0], acc[a][b + 1][1]), y1 = pk(acc[a][b + 1][2], acc[a][b + 1][3]);
-                        // rows (16-lane groups) 1 and 3 of x trade places with rows 0 and 2 of y: every lane then
-                        // holds 8 consecutive n
                         const auto s0 = __builtin_amdgcn_permlane16_swap(x0, y0, false, false);
                         const auto s1 = __builtin_amdgcn_permlane16_swap(x1, y1, false, false);
-                        const rs_u32x4 o = rs_u32x4{s0[0], s1[0], s0[1], s1[1]};
-                        if (m < g.M && ABL != 3) {
-                            if (g.nts) __builtin_nontemporal_store(o, reinterpret_cast<rs_u32x4*>(crow + b * 16));
-                            else *reinterpret_cast<rs_u32x4*>(crow + b * 16) = o;
+                        o[b / 2] = rs_u32x4{s0[0], s1[0], s0[1], s1[1]};
+                    }
+                    const int cq = (q & 1) * 16 + (q >> 1) * 8;
+                    {
+                        __hip_bfloat16* crow = reinterpret_cast<__hip_bfloat16*>(g.C) + (int64_t)m * g.ldc + n0 + cq;
+#pragma unroll
+                        for (int b = 0; b < NB; b += 2) {
+                            if (m < g.M) *reinterpret_cast<rs_u32x4*>(crow + b * 16) = o[b / 2];
                         }
                     }
                 }
@@ -212,7 +235,7 @@ __global__ __launch_bounds__(768, 3) void gemm_nt_rs_kernel(RsArgs g) {
     }
 }
 
-template <int BM, int BN, int WMW, int NST, int ABL = 0>
+template <int BM, int BN, int WMW, int NSTA>
 static int launch_nt_rs(const void* A, const void* B, void* C, int M, int N, int K, int64_t lda, int64_t ldb, int64_t ldc,
                         int out_dtype, hipStream_t s) {
     RsArgs g;
@@ -229,10 +252,8 @@ static int launch_nt_rs(const void* A, const void* B, void* C, int M, int N, int
         const double cost = (double)c * M * K + (8.0 / c) * N * K;
         if (best < 0 || cost < best) best = cost, g.gcols = c;
     }
-    if (g_lab[0] > 0 && g.ntn % g_lab[0] == 0) g.gcols = g_lab[0];
-    g.nts = g_lab[1];
-    if (out_dtype == SP_F32) hipLaunchKernelGGL((gemm_nt_rs_kernel<BM, BN, WMW, NST, SP_F32, ABL>), dim3(256), dim3(768), 0, s, g);
-    else hipLaunchKernelGGL((gemm_nt_rs_kernel<BM, BN, WMW, NST, SP_BF16, ABL>), dim3(256), dim3(768), 0, s, g);
+    if (out_dtype == SP_F32) hipLaunchKernelGGL((gemm_nt_rs_kernel<BM, BN, WMW, NSTA, SP_F32>), dim3(256), dim3(768), 0, s, g);
+    else hipLaunchKernelGGL((gemm_nt_rs_kernel<BM, BN, WMW, NSTA, SP_BF16>), dim3(256), dim3(768), 0, s, g);
     return check_launch("gemm_nt_rs_kernel");
 }
 
@@ -247,16 +268,8 @@ bool nt_rs_ok(int M, int N, int K, int64_t lda, int64_t ldb, int64_t ldc, const 
 int gemm_nt_rs(const void* A, const void* B, void* C, int M, int N, int K, int64_t lda, int64_t ldb, int64_t ldc,
                int out_dtype, int variant, hipStream_t s) {
     switch (variant) {
-        case 0: return launch_nt_rs<192, 256, 2, 2>(A, B, C, M, N, K, lda, ldb, ldc, out_dtype, s);
-        case 1: return launch_nt_rs<128, 256, 2, 3>(A, B, C, M, N, K, lda, ldb, ldc, out_dtype, s);
-        case 2: return launch_nt_rs<192, 192, 4, 3>(A, B, C, M, N, K, lda, ldb, ldc, out_dtype, s);
-        case 3: return launch_nt_rs<256, 128, 4, 3>(A, B, C, M, N, K, lda, ldb, ldc, out_dtype, s);
-        case 10: return launch_nt_rs<192, 256, 2, 2, 1>(A, B, C, M, N, K, lda, ldb, ldc, out_dtype, s);
-        case 20: return launch_nt_rs<192, 256, 2, 2, 2>(A, B, C, M, N, K, lda, ldb, ldc, out_dtype, s);
-        case 30: return launch_nt_rs<192, 256, 2, 2, 3>(A, B, C, M, N, K, lda, ldb, ldc, out_dtype, s);
-        case 11: return launch_nt_rs<128, 256, 2, 3, 1>(A, B, C, M, N, K, lda, ldb, ldc, out_dtype, s);
-        case 21: return launch_nt_rs<128, 256, 2, 3, 2>(A, B, C, M, N, K, lda, ldb, ldc, out_dtype, s);
-        case 31: return launch_nt_rs<128, 256, 2, 3, 3>(A, B, C, M, N, K, lda, ldb, ldc, out_dtype, s);
+        case 0: return launch_nt_rs<192, 256, 2, 3>(A, B, C, M, N, K, lda, ldb, ldc, out_dtype, s);     // N % 256 == 0
+        case 3: return launch_nt_rs<256, 128, 4, 3>(A, B, C, M, N, K, lda, ldb, ldc, out_dtype, s);     // N % 128 == 0
         default: return fail(SP_EINVAL, "gemm_nt_rs: variant %d", variant);
     }
 }
@@ -283,14 +296,15 @@ struct TnArgs {
 };
 
 typedef short rs_s16x4 __attribute__((ext_vector_type(4)));
+struct TnCursor { int item, step, steps, soff; };
 
-template <int ABL = 0>
 __global__ __launch_bounds__(768, 3) void gemm_tn_rs_kernel(TnArgs g) {
-    constexpr int BI = 256, BJ = 256, NST = 2;
+    constexpr int BI = 256, BJ = 256;
+    constexpr int NSX = 2, NSG = 3;               // ring depths: X panels two stages, G panels (gU: the larger, colder operand) three
     constexpr int MB = 8, NB = 4;                 // wave tile 128 (i) x 64 (j), waves 2 (i) x 4 (j)
-    constexpr int PART = 64 * 512, STAGE = 2 * PART;
-    constexpr int PER = 16;                       // DMA instructions per loader wave and stage
-    __shared__ __attribute__((aligned(1024))) unsigned char smem[NST * STAGE];
+    constexpr int PART = 64 * 512, GOFF = NSX * PART;
+    constexpr int PER = 8;                        // DMA instructions per loader wave, stage and operand
+    __shared__ __attribute__((aligned(1024))) unsigned char smem[(NSX + NSG) * PART];
 
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -324,41 +338,51 @@ __global__ __launch_bounds__(768, 3) void gemm_tn_rs_kernel(TnArgs g) {
             vx[i] = k * g.ldx * 2 + c * 16;
             vg[i] = k * g.ldg * 2 + c * 16;
         }
-        int litem = first, lstep = 0, lsteps = item_steps(first), sx = 0, sg = 0;
-        auto set_item = [&](int item) {
-            const int z = item / ntiles, t = item % ntiles;
-            const int k0 = z * g.steps_per * 64;
-            sx = (k0 * g.ldx + (t % g.nti) * BI) * 2;
-            sg = (k0 * g.ldg + (t / g.nti) * BJ) * 2;
-        };
-        set_item(first);
-        auto issue = [&](int stage) {
-            if (ABL == 2) return;
-            unsigned char* st = smem + stage * STAGE + lw * 1024;
-#pragma unroll
-            for (int i = 0; i < 8; ++i)
-                __builtin_amdgcn_raw_ptr_buffer_load_lds(rx, (rs_lptr_t)(st + i * 4096), 16, vx[i], sx, 0, 0);
-#pragma unroll
-            for (int i = 0; i < 8; ++i)
-                __builtin_amdgcn_raw_ptr_buffer_load_lds(rg, (rs_lptr_t)(st + PART + i * 4096), 16, vg[i], sg, 0, 0);
-            sx += 64 * g.ldx * 2;
-            sg += 64 * g.ldg * 2;
-            if (++lstep == lsteps) {
-                lstep = 0;
-                litem += nslots;
-                if (litem < x_hi) { set_item(litem); lsteps = item_steps(litem); }
-                else lsteps = 1 << 30;      // past the last item: rows beyond the buffers read as zeros
+        // one cursor per operand over the flat (item, k step) sequence: G runs one step further ahead than X
+        auto set_cur = [&](TnCursor& c, int item, bool isG) {
+            c.item = item; c.step = 0;
+            if (item < x_hi) {
+                const int z = item / ntiles, t = item % ntiles;
+                const int k0 = z * g.steps_per * 64;
+                c.soff = isG ? (k0 * g.ldg + (t / g.nti) * BJ) * 2 : (k0 * g.ldx + (t % g.nti) * BI) * 2;
+                c.steps = item_steps(item);
+            } else {
+                c.steps = 1 << 30;      // past the last item: keeps reading the rows that follow (zeros beyond the buffer)
             }
         };
+        TnCursor cx, cg;
+        set_cur(cx, first, false);
+        set_cur(cg, first, true);
+        auto issueX = [&](int stage) {
+            unsigned char* st = smem + stage * PART + lw * 1024;
 #pragma unroll
-        for (int s0 = 0; s0 < NST - 1; ++s0) issue(s0);
-        int fill = NST - 1;
+            for (int i = 0; i < 8; ++i)
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rx, (rs_lptr_t)(st + i * 4096), 16, vx[i], cx.soff, 0, 0);
+            cx.soff += 64 * g.ldx * 2;
+            if (++cx.step == cx.steps) set_cur(cx, cx.item + nslots, false);
+        };
+        auto issueG = [&](int stage) {
+            unsigned char* st = smem + GOFF + stage * PART + lw * 1024;
+#pragma unroll
+            for (int i = 0; i < 8; ++i)
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rg, (rs_lptr_t)(st + i * 4096), 16, vg[i], cg.soff, 0, 0);
+            cg.soff += 64 * g.ldg * 2;
+            if (++cg.step == cg.steps) set_cur(cg, cg.item + nslots, true);
+        };
+        issueG(0);
+        issueG(1);
+        issueX(0);
+        int fx = 1, fg = 2;
         for (int step = 0; step < total; ++step) {
-            asm volatile("s_waitcnt vmcnt(%0)" ::"n"((NST - 2) * PER) : "memory");
+            // in flight may stay: this wave's share of G(step + 1), issued after X(step)
+            if (step == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PER) : "memory");
             __builtin_amdgcn_s_barrier();
             asm volatile("" ::: "memory");
-            issue(fill);
-            fill = fill + 1 == NST ? 0 : fill + 1;
+            issueX(fx);                      // X(step + 1)
+            issueG(fg);                      // G(step + 2)
+            fx ^= 1;
+            fg = fg + 1 == NSG ? 0 : fg + 1;
         }
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         return;
@@ -376,7 +400,7 @@ __global__ __launch_bounds__(768, 3) void gemm_tn_rs_kernel(TnArgs g) {
 #pragma unroll
     for (int a = 0; a < MB; ++a) ax[a] = lds0 + rowoff + ((((wi * 8 + a) & 15) ^ sk) << 5);
 #pragma unroll
-    for (int b = 0; b < NB; ++b) ag[b] = lds0 + PART + rowoff + ((((wj * 4 + b) & 15) ^ sk) << 5);
+    for (int b = 0; b < NB; ++b) ag[b] = lds0 + GOFF + rowoff + ((((wj * 4 + b) & 15) ^ sk) << 5);
 
     rs_f32x4 acc[MB][NB];
 #pragma unroll
@@ -393,26 +417,26 @@ __global__ __launch_bounds__(768, 3) void gemm_tn_rs_kernel(TnArgs g) {
         return __builtin_bit_cast(rs_bf16x8, v);
     };
 
-    int citem = first, ck = 0, csteps = item_steps(first), stage = 0;
+    int citem = first, ck = 0, csteps = item_steps(first), sx = 0, sg = 0;
     for (int step = 0; step < total; ++step) {
         __builtin_amdgcn_s_barrier();
         asm volatile("" ::: "memory");
-        const uint32_t so = stage * STAGE;
 #pragma unroll
-        for (int kk = 0; kk < (ABL == 1 ? 0 : 2); ++kk) {
-            const uint32_t ko = so + kk * 32 * 512;
+        for (int kk = 0; kk < 2; ++kk) {
+            const uint32_t kx = sx * PART + kk * 32 * 512, kg = sg * PART + kk * 32 * 512;
             rs_bf16x8 Pf[NB];
 #pragma unroll
-            for (int b = 0; b < NB; ++b) Pf[b] = frag(ag[b] + ko);
+            for (int b = 0; b < NB; ++b) Pf[b] = frag(ag[b] + kg);
 #pragma unroll
             for (int a = 0; a < MB; ++a) {
-                const rs_bf16x8 Q = frag(ax[a] + ko);
+                const rs_bf16x8 Q = frag(ax[a] + kx);
 #pragma unroll
                 for (int b = 0; b < NB; ++b) acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(Pf[b], Q, acc[a][b], 0, 0, 0);
             }
         }
         asm volatile("" ::: "memory");
-        stage = stage + 1 == NST ? 0 : stage + 1;
+        sx ^= 1;
+        sg = sg + 1 == NSG ? 0 : sg + 1;
         if (++ck == csteps) {
             // D[row = j][col = i]: lane = (i = li, q), register e -> j = 4 q + e
             const int z = citem / ntiles, t = citem % ntiles;
@@ -423,7 +447,7 @@ __global__ __launch_bounds__(768, 3) void gemm_tn_rs_kernel(TnArgs g) {
                 float* crow = Pz + (int64_t)(i0 + a * 16 + li) * g.ldp + j0 + 4 * q;
 #pragma unroll
                 for (int b = 0; b < NB; ++b) {
-                    if (ABL != 3) *reinterpret_cast<rs_f32x4*>(crow + b * 16) = acc[a][b];
+                    *reinterpret_cast<rs_f32x4*>(crow + b * 16) = acc[a][b];
                     acc[a][b] = rs_f32x4{0.f, 0.f, 0.f, 0.f};
                 }
             }
@@ -458,38 +482,9 @@ int gemm_tn_rs(const void* X, const void* G, float* P, int Mi, int Nj, int K, in
     g.ldp = ldp; g.slab = slab_stride;
     g.nti = Mi / 256; g.ntj = Nj / 256; g.S = S;
     g.steps_per = ((K + 63) / 64 + S - 1) / S;
-    switch (variant) {
-        case 0: hipLaunchKernelGGL((gemm_tn_rs_kernel<0>), dim3(256), dim3(768), 0, s, g); break;
-        case 10: hipLaunchKernelGGL((gemm_tn_rs_kernel<1>), dim3(256), dim3(768), 0, s, g); break;
-        case 20: hipLaunchKernelGGL((gemm_tn_rs_kernel<2>), dim3(256), dim3(768), 0, s, g); break;
-        case 30: hipLaunchKernelGGL((gemm_tn_rs_kernel<3>), dim3(256), dim3(768), 0, s, g); break;
-        default: return fail(SP_EINVAL, "gemm_tn_rs: variant %d", variant);
-    }
+    (void)variant;
+    hipLaunchKernelGGL(gemm_tn_rs_kernel, dim3(256), dim3(768), 0, s, g);
     return check_launch("gemm_tn_rs_kernel");
 }
 
 }  // namespace sp
-
-extern "C" int sp_lab_gemm_tn(const void* X, const void* G, void* P, int Mi, int Nj, int K, int64_t ldx, int64_t ldg,
-                              int S, int variant, void* stream) {
-    using namespace sp;
-    SP_CHECK_ARG(tn_rs_ok(Mi, Nj, K, ldx, ldg, X, G, P) && S >= 1 && S <= 64, "sp_lab_gemm_tn: shape not supported");
-    return gemm_tn_rs(X, G, (float*)P, Mi, Nj, K, ldx, ldg, Nj, (int64_t)Mi * Nj, S, variant, reinterpret_cast<hipStream_t>(stream));
-}
-
-namespace sp {
-}  // namespace sp
-
-extern "C" void sp_lab_set(int key, int value) {
-    if (key >= 0 && key < 8) sp::g_lab[key] = value;
-}
-
-// development entry point (tools/gemm_lab.py): one named variant of the role-split kernels
-extern "C" int sp_lab_gemm_nt(const void* A, const void* B, void* C, int M, int N, int K, int64_t lda, int64_t ldb,
-                              int64_t ldc, int out_dtype, int variant, void* stream) {
-    using namespace sp;
-    static const int bn[] = {256, 256, 192, 128};
-    SP_CHECK_ARG(variant >= 0 && variant % 10 < 4, "sp_lab_gemm_nt: variant %d", variant);
-    SP_CHECK_ARG(nt_rs_ok(M, N, K, lda, ldb, ldc, A, B, C, out_dtype, bn[variant % 10]), "sp_lab_gemm_nt: shape not supported");
-    return gemm_nt_rs(A, B, C, M, N, K, lda, ldb, ldc, out_dtype, variant, reinterpret_cast<hipStream_t>(stream));
-}

@@ -54,8 +54,14 @@ int sp_version(void);
  * reflect padding needs it; the caller checks) and T_b = 1 + N_b/160 frames.  out is
  * [B, 80, T_max] f32 (= [B,1,80,T_max]); frames t >= T_b are written as 0.  masks: DEVICE
  * int32 [B][4] = (f0, fw, t0, tw) or NULL; rows [f0,f0+fw) and frames [t0,t0+tw) of utterance b
- * become 0.  flags: bit0 = natural log of (mel + 1e-6) (not reference behaviour; 0 = parity);
- * bit2 (value 4) = wav is int16.
+ * become 0.  flags (0 = the reference's magnitude mel, the parity mode): bit0 = natural log of (mel + 1e-6);
+ * bit1 (value 2) = per-utterance normalisation, applied after the log stage if that is on: every mel row of
+ * every utterance is shifted and scaled to zero mean and unit (biased) variance over the utterance's T_b valid
+ * frames, y = (x - mean) / sqrt(var + 1e-5); the SpecAugment bands are zeroed after the statistics were taken and
+ * padding frames stay 0 (a second, light launch on the same stream).  Neither stage exists in the reference
+ * (SURVEY D1); both are the optional stages BASELINE's north_star names.  bit2 (value 4) = wav is int16.
+ * sp_melspec_plan copies the plan from pageable host memory and waits for that copy on `stream` before it
+ * returns (its host staging buffer is reused by the next call): the one entry point that synchronises.
  * --------------------------------------------------------------------------------------- */
 size_t sp_melspec_plan_bytes(void);
 int sp_melspec_plan(const float* fbank_host, void* plan_dev, void* stream);
@@ -149,9 +155,10 @@ int sp_sru_bwd(const void* U, const void* xres, const float* wc, const float* bi
  * sp_sumsq_f32: out[0] = sum x_i^2; out must hold SP_SUMSQ_WORDS floats (out[1..] are per-workgroup
  * partials, summed in a fixed order: the result is bit-reproducible, so data-parallel replicas that
  * hold the same reduced gradient derive the same clip coefficient and stay identical).
- * sp_adam_step_f32: bias-corrected Adam, step >= 1.  Gradient used = g * clip / grad_div where
- * clip = min(1, max_norm / (sqrt(sumsq[0]) + 1e-6)) if sumsq != NULL and max_norm > 0, else 1
- * (clip_grad_norm_ semantics, no host sync).  decoupled != 0: p *= 1 - lr*wd after the update
+ * sp_adam_step_f32: bias-corrected Adam, step >= 1.  Gradient used = clip * g / grad_div where
+ * clip = min(1, max_norm / (sqrt(sumsq[0]) / |grad_div| + 1e-6)) if sumsq != NULL and max_norm > 0, else
+ * 1: clip_grad_norm_ applied to g / grad_div, the gradient the update uses (data parallel: g is the sum
+ * over the ranks, grad_div the world size), no host sync.  decoupled != 0: p *= 1 - lr*wd after the update
  * (bitsandbytes kernels); 0: g += wd * p (L2).
  * --------------------------------------------------------------------------------------- */
 #define SP_SUMSQ_WORDS 1025

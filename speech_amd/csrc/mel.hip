@@ -13,7 +13,7 @@
 //            tiles, only over the 4-bin blocks where the 16-mel tile's filters are non-zero
 //   phase 5  masked / padded store, [B][80][T_max]
 // HBM traffic: every sample is read once from HBM (the 2.5x frame overlap is served by L1/L2),
-// every output element written once.  LDS: 19.2 KB per wave, 77 KB per block, 2 blocks per CU.
+// every output element written once.  LDS: 12.8 KB per wave (the magnitudes alias the FFT buffer), 3 blocks per CU.
 #include <cstring>
 
 #include "common.h"
@@ -254,6 +254,36 @@ __global__ __launch_bounds__(64 * kWPB, 3) void melspec_kernel(
     }
 }
 
+// Per-utterance normalisation (flags bit 1), a light second pass over the features the first pass left in
+// L2 / HBM: one wave per (utterance, mel row), mean and biased variance over the utterance's T_b valid frames
+// taken in two sweeps of the row (sum, then sum of squared deviations: no cancellation), y = (x - mean) *
+// rsqrt(var + 1e-5); SpecAugment bands are applied here (the statistics see the unmasked features), padding
+// frames stay 0.
+__global__ __launch_bounds__(256) void melnorm_kernel(float* __restrict__ out, const int64_t* __restrict__ offs, int T_max,
+                                                        const int32_t* __restrict__ masks) {
+    const int b = blockIdx.y, lane = threadIdx.x & 63;
+    const int mel = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (mel >= kMels) return;
+    const int Tb = min((int)((offs[b + 1] - offs[b]) / kHop) + 1, T_max);
+    float* row = out + ((int64_t)b * kMels + mel) * T_max;
+    float s = 0.f;
+    for (int t = lane; t < Tb; t += 64) s += row[t];
+    const float mean = wave_sum(s) / (float)Tb;
+    float q = 0.f;
+    for (int t = lane; t < Tb; t += 64) {
+        const float dlt = row[t] - mean;
+        q += dlt * dlt;
+    }
+    const float rstd = rsqrtf(wave_sum(q) / (float)Tb + 1e-5f);
+    int mf0 = 0, mfw = 0, mt0 = 0, mtw = 0;
+    if (masks) { mf0 = masks[4 * b]; mfw = masks[4 * b + 1]; mt0 = masks[4 * b + 2]; mtw = masks[4 * b + 3]; }
+    const bool frow = mel >= mf0 && mel < mf0 + mfw;
+    for (int t = lane; t < Tb; t += 64) {
+        const bool m = frow || (t >= mt0 && t < mt0 + mtw);
+        row[t] = m ? 0.f : (row[t] - mean) * rstd;
+    }
+}
+
 }  // namespace sp
 
 extern "C" size_t sp_melspec_plan_bytes(void) { return sizeof(sp::MelPlan); }
@@ -309,15 +339,22 @@ extern "C" int sp_melspec_fwd(const void* wav, const int64_t* wav_offsets, int B
     if (B == 0 || T_max == 0) return SP_OK;
     SP_CHECK_ARG(wav && wav_offsets && plan_dev && out, "sp_melspec_fwd: null pointer");
     SP_CHECK_ARG(B <= 65535, "sp_melspec_fwd: B=%d exceeds grid limit", B);
+    SP_CHECK_ARG((flags & ~7) == 0, "sp_melspec_fwd: unknown flag bits in %d", flags);
     const int per_block = kF * kWPB;
     dim3 grid((T_max + per_block - 1) / per_block, B);
+    // with the normalisation pass the SpecAugment bands are applied there, after the statistics
+    const int32_t* masks1 = (flags & 2) ? nullptr : masks;
     if (flags & 4)
         hipLaunchKernelGGL((melspec_kernel<int16_t>), grid, dim3(64 * kWPB), 0, reinterpret_cast<hipStream_t>(stream),
-                           (const int16_t*)wav, wav_offsets, T_max, reinterpret_cast<const MelPlan*>(plan_dev), masks,
+                           (const int16_t*)wav, wav_offsets, T_max, reinterpret_cast<const MelPlan*>(plan_dev), masks1,
                            flags, out);
     else
         hipLaunchKernelGGL((melspec_kernel<float>), grid, dim3(64 * kWPB), 0, reinterpret_cast<hipStream_t>(stream),
-                           (const float*)wav, wav_offsets, T_max, reinterpret_cast<const MelPlan*>(plan_dev), masks,
+                           (const float*)wav, wav_offsets, T_max, reinterpret_cast<const MelPlan*>(plan_dev), masks1,
                            flags, out);
-    return check_launch("melspec_kernel");
+    int rc = check_launch("melspec_kernel");
+    if (rc || !(flags & 2)) return rc;
+    hipLaunchKernelGGL(melnorm_kernel, dim3((kMels + 3) / 4, B), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), out,
+                       wav_offsets, T_max, masks);
+    return check_launch("melnorm_kernel");
 }

@@ -63,11 +63,13 @@ __global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ p, const 
                                                     float* __restrict__ m, float* __restrict__ v,
                                                     int64_t n, AdamArgs a,
                                                     const float* __restrict__ sumsq) {
-    // clip coefficient as torch.nn.utils.clip_grad_norm_: max_norm / (norm + 1e-6), capped at 1;
-    // the norm is taken on the gradient as stored (train.py:81 clips before unscaling).
+    // clip coefficient as torch.nn.utils.clip_grad_norm_: max_norm / (norm + 1e-6), capped at 1, where
+    // the norm is that of the gradient the update USES, g / grad_div (data parallel: the buffer holds the
+    // SUM over the ranks and grad_div = world, so the mean gradient is what gets clipped -- the same
+    // update whatever the world size).
     float gscale = 1.f;
     if (sumsq && a.max_norm > 0.f) {
-        const float norm = sqrtf(sumsq[0]);
+        const float norm = sqrtf(sumsq[0]) / fabsf(a.grad_div);
         gscale = fminf(1.f, a.max_norm / (norm + 1e-6f));
     }
     gscale /= a.grad_div;

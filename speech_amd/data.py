@@ -199,6 +199,25 @@ def _remap(path, root_map):
     return path
 
 
+class IBMDataset(torch.utils.data.Dataset):
+    """data.py:82-102: every *.wav under one directory with its transcript in the .txt next to it, one clip
+    per item (the loader batches it).  root replaces the reference's hard-coded "/hd1/ibm"."""
+
+    def __init__(self, root="/hd1/ibm"):
+        super().__init__()
+        self.paths = sorted(os.path.join(root, f) for f in os.listdir(root) if f.endswith("wav"))
+
+    def __len__(self):
+        return len(self.paths)
+
+    def __getitem__(self, i):
+        audio_path = self.paths[i]
+        waveform, _ = load_audio(audio_path)
+        with open(audio_path.replace(".wav", ".txt")) as f:
+            utterance = f.read().strip()
+        return waveform, utterance
+
+
 class SortedLibriSpeech(SortedDataset):
     """data.py:105-115.  root_map replaces the reference's hard-coded "/data" -> "/hd1"."""
 

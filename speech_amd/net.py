@@ -184,12 +184,29 @@ class SRModel(nn.Module):
         return ops.classifier_ctc_loss(self.encode(x), self.classifier[1].weight, labels, label_lengths, 0,
                                        max_label_len)
 
+    # keys whose presence depends on the version of the `sru` package / torch that wrote the checkpoint and that
+    # carry no trained values: sru registers `scale_x` (1.0 unless rescale=True; net.py:66 passes rescale=False)
+    # as a buffer in some releases only; BatchNorm's step counter is bookkeeping
+    _OPTIONAL_KEYS = (".scale_x", ".num_batches_tracked")
+
     def load_checkpoint(self, obj):
         """Accept both checkpoint shapes of the reference: the dict train.py:171-178 saves
         ({"epoch","model_state_dict","optimizer_state_dict"}) and the bare state_dict that
-        scripts/predict.py:35 and scripts/eval_dataset.py:119 load."""
+        scripts/predict.py:35 and scripts/eval_dataset.py:119 load.  Keys in _OPTIONAL_KEYS may be missing or
+        extra (reported in the result, never an error); any other mismatch raises, as load_state_dict does.
+        The key layout of the sru layers is recalled from the package, not verified against a reference
+        checkpoint (none ships with the reference): parity unpinned."""
         sd = obj["model_state_dict"] if isinstance(obj, dict) and "model_state_dict" in obj else obj
-        return self.load_state_dict(sd)
+        own = self.state_dict()
+        optional = lambda k: k.endswith(self._OPTIONAL_KEYS)      # noqa: E731
+        missing = [k for k in own if k not in sd]
+        unexpected = [k for k in sd if k not in own]
+        bad = [k for k in missing + unexpected if not optional(k)]
+        if bad:
+            raise RuntimeError("checkpoint does not match SRModel: missing " + str([k for k in missing if not optional(k)])
+                               + ", unexpected " + str([k for k in unexpected if not optional(k)]))
+        self.load_state_dict({k: v for k, v in sd.items() if k in own}, strict=False)
+        return torch.nn.modules.module._IncompatibleKeys(missing, unexpected)
 
 
 def out_frames(t):

@@ -1,6 +1,6 @@
 """Training / evaluation loop -- same entry point and flags as the reference's train.py
 (--one_iter --datasets --multiplier --device --weight_decay --clip_grad_norm --dropout
---learning_rate --num_epochs --projection_size), plus --synthetic / --steps / --dtype.
+--learning_rate --num_epochs --projection_size), plus --synthetic / --steps / --dtype / --root_map / --manifest_root / --ibm_root / --resume.
 
 What changes against train.py:42-304:
   * features come from the fused HIP frontend on the GPU (data.collate_fn), not DataLoader workers;
@@ -124,6 +124,10 @@ class BucketedAllReduce:
     def __init__(self, opt, group=None, bucket_mb=25.0):
         self.opt, self.group = opt, group
         self.world = dist.get_world_size(group)
+        # gloo (CPU tests, two ranks on one card) stages device tensors through the host on streams of its own;
+        # draining the launch stream first keeps that path to plain synchronous copies.  RCCL stays fully
+        # asynchronous.
+        self.drain = dist.get_backend(group) == "gloo" and opt.flat_grad.is_cuda
         cap = int(bucket_mb * 1024 * 1024 / 4)
         self.buckets = []   # [lo, hi, n_params]
         self.bucket_of = {}
@@ -157,9 +161,14 @@ class BucketedAllReduce:
             b = self.bucket_of[idx]
             self.pending[b] -= 1
             if self.pending[b] == 0:
-                lo, hi, _ = self.buckets[b]
-                self.handles.append(dist.all_reduce(self.opt.flat_grad[lo:hi], group=self.group, async_op=True))
+                self._launch(b)
         return hook
+
+    def _launch(self, b):
+        lo, hi, _ = self.buckets[b]
+        if self.drain:
+            torch.cuda.current_stream().synchronize()
+        self.handles.append(dist.all_reduce(self.opt.flat_grad[lo:hi], group=self.group, async_op=True))
 
     def param_ready(self, p):
         """For gradients a backward kernel wrote straight into the arena (ops.GradSink): autograd's
@@ -172,8 +181,7 @@ class BucketedAllReduce:
         """Call after backward: launch whatever did not fire (unused parameters), wait for all."""
         for b, left in enumerate(self.pending):
             if left > 0:
-                lo, hi, _ = self.buckets[b]
-                self.handles.append(dist.all_reduce(self.opt.flat_grad[lo:hi], group=self.group, async_op=True))
+                self._launch(b)
         for h in self.handles:
             h.wait()
         self.handles = []
@@ -234,23 +242,33 @@ def train(batch_size, model, train_loader, optimizer, scheduler, epoch, iter_met
 
 
 @torch.no_grad()
-def eval_dataset(model, loader, name, log=print):
-    """train.py:105-144: mean loss, unweighted mean of per-utterance CER / WER."""
+def eval_dataset(model, loader, name, log=print, dtype=torch.float32):
+    """train.py:105-144: mean loss, unweighted mean of per-utterance CER / WER.  The reference evaluates
+    outside autocast, i.e. in fp32 (train.py:162-168): `dtype` is the activation type of the SRU stack and
+    the classifier for this pass (None = the model's training type; the conv stack's kernels keep bf16
+    activations either way)."""
     model.eval()
+    saved = getattr(model, "compute_dtype", None)
+    if dtype is not None and saved is not None:
+        model.compute_dtype = dtype
     eval_loss, eval_cer, eval_wer, n = 0.0, [], [], 0
-    for batch in loader:
-        spectrograms, labels, label_lengths = batch
-        spectrograms, labels, label_lengths = spectrograms.cuda(), labels.cuda(), label_lengths.cuda()
-        output = model(spectrograms).float()
-        B, Tp, _ = output.shape
-        input_lengths = torch.full((B,), Tp, dtype=torch.int32, device=output.device)
-        loss, _, _ = ops.ctc_fwd_bwd(output, labels, input_lengths, label_lengths, want_grad=False)
-        eval_loss += float(loss)
-        n += 1
-        preds, targets = decoder.greedy_decoder(output, labels, label_lengths)
-        for tgt, pred in zip(targets, preds):
-            eval_cer.append(decoder.cer(tgt, pred))
-            eval_wer.append(decoder.wer(tgt, pred))
+    try:
+        for batch in loader:
+            spectrograms, labels, label_lengths = batch
+            spectrograms, labels, label_lengths = spectrograms.cuda(), labels.cuda(), label_lengths.cuda()
+            output = model(spectrograms).float()
+            B, Tp, _ = output.shape
+            input_lengths = torch.full((B,), Tp, dtype=torch.int32, device=output.device)
+            loss, _, _ = ops.ctc_fwd_bwd(output, labels, input_lengths, label_lengths, want_grad=False)
+            eval_loss += float(loss)
+            n += 1
+            preds, targets = decoder.greedy_decoder(output, labels, label_lengths)
+            for tgt, pred in zip(targets, preds):
+                eval_cer.append(decoder.cer(tgt, pred))
+                eval_wer.append(decoder.wer(tgt, pred))
+    finally:
+        if saved is not None:
+            model.compute_dtype = saved
     avg_cer = sum(eval_cer) / len(eval_cer)
     avg_wer = sum(eval_wer) / len(eval_wer)
     log("{}: Average loss: {:.4f}, Average CER: {:4f} Average WER: {:.4f}\n".format(
@@ -276,6 +294,101 @@ def setup_distributed():
     return int(os.environ.get("RANK", "0")), world
 
 
+# train.py:182-192: the reference's manifest list (relative to the working directory, like there)
+TV_TRAIN_DATASETS_PATHS = [
+    "datasets/first/sorted_train_cer_0.1.pkl",
+    "datasets/second/sorted_train_cer_0.1.pkl",
+    "datasets/third/sorted_train_cer_0.1.pkl",
+    "datasets/fourth/sorted_train_cer_0.1.pkl",
+    "datasets/fifth/sorted_train_cer_0.1.pkl",
+    "datasets/sixth/sorted_train_cer_0.1.pkl",
+    "datasets/gigaspeech/sorted_train_youtube_filtered.pkl",
+    "datasets/gigaspeech/sorted_train_podcast_filtered.pkl",
+    "datasets/gigaspeech/sorted_train_audiobook_filtered.pkl",
+]
+LIBRISPEECH_TRAIN_PATH = "datasets/librispeech/sorted_train_librispeech.pkl"
+
+
+class RankBatchSampler(torch.utils.data.Sampler):
+    """This rank's share of a SortedDataset's batch indices: one permutation per epoch that every rank derives
+    from the same seed, cut to a multiple of the world size, so that all ranks take the SAME number of steps (a
+    rank with one batch more would wait forever in its bucket all-reduces)."""
+
+    def __init__(self, n_batches, rank=0, world=1, shuffle=True, seed=7):
+        self.n, self.rank, self.world, self.shuffle, self.seed, self.epoch = n_batches, rank, world, shuffle, seed, 0
+
+    def set_epoch(self, epoch):
+        self.epoch = epoch
+
+    def __len__(self):
+        return self.n // self.world
+
+    def __iter__(self):
+        if self.shuffle:
+            order = torch.randperm(self.n, generator=torch.Generator().manual_seed(self.seed + self.epoch)).tolist()
+        else:
+            order = list(range(self.n))
+        return iter(order[self.rank:len(self) * self.world:self.world])
+
+
+class FeaturizingLoader:
+    """DataLoader workers read and decode the clips (file IO, as in the reference); the featuriser runs on the
+    GPU, which forked workers must not touch, so collate_fn is applied here, in the training process."""
+
+    def __init__(self, loader, data_type):
+        self.loader, self.data_type = loader, data_type
+        self.dataset = loader.dataset
+
+    def __len__(self):
+        return len(self.loader)
+
+    def __iter__(self):
+        for clips in self.loader:
+            yield data.collate_fn(clips, self.data_type)
+
+
+def _clips(batch):
+    return batch
+
+
+def build_loaders(hparams, rank, world):
+    """(train_loader, sampler, [(name, eval_loader), ...]) as train.py:202-239 builds them: CombinedTVLibriSpeech for
+    training, SortedTV for the "tv" evaluation, IBMDataset for the "ibm" one whose CER picks the checkpoint."""
+    bs = hparams["batch_size"]
+    workers = hparams.get("num_workers", 6)
+    if hparams["synthetic"]:
+        train_set = data.SyntheticSorted(hparams["synthetic_clips"], bs, seed=7)
+        tv_eval = data.SyntheticSorted(max(bs, hparams["synthetic_clips"] // 8), bs, seed=11, max_s=6.0)
+        ibm_eval, workers = None, 0
+    else:
+        datasets = hparams["datasets"].split("-")
+        assert "tv" in datasets and "libri" in datasets
+        device = hparams.get("device") or 0
+        root_map = hparams.get("root_map")
+        prefix = hparams.get("manifest_root", "")
+        tv_paths = [os.path.join(prefix, p) for p in TV_TRAIN_DATASETS_PATHS]
+        if hparams.get("tv_manifests"):
+            tv_paths = list(hparams["tv_manifests"])
+        train_set = data.CombinedTVLibriSpeech(os.path.join(prefix, LIBRISPEECH_TRAIN_PATH), tv_paths, bs, device, root_map)
+        # train.py:208-212 swaps "train" for "eval" in the manifest NAME (a prefix directory may say "train" too)
+        tv_eval_paths = [os.path.join(os.path.dirname(p), os.path.basename(p).replace("train", "eval"))
+                         for p in tv_paths if "gigaspeech" not in p]
+        tv_eval = data.SortedTV(tv_eval_paths, bs, device, root_map)
+        ibm_eval = data.IBMDataset(hparams.get("ibm_root", "/hd1/ibm"))
+    sampler = RankBatchSampler(len(train_set), rank, world, shuffle=True)
+    if hparams["steps"]:
+        sampler.n = min(sampler.n, hparams["steps"] * world)
+    train_loader = FeaturizingLoader(torch.utils.data.DataLoader(
+        train_set, batch_size=None, sampler=sampler, collate_fn=_clips, num_workers=workers, pin_memory=False), "train")
+    evals = [("tv", FeaturizingLoader(torch.utils.data.DataLoader(
+        tv_eval, batch_size=None, shuffle=True, collate_fn=_clips, num_workers=min(workers, 4)), "valid"))]
+    if ibm_eval is not None:
+        evals.append(("ibm", FeaturizingLoader(torch.utils.data.DataLoader(
+            ibm_eval, batch_size=32 * hparams["multiplier"] * 2, shuffle=False, collate_fn=_clips,
+            num_workers=min(workers, 4)), "valid")))
+    return train_loader, sampler, evals
+
+
 def main(hparams):
     rank, world = setup_distributed()
     torch.manual_seed(7 + rank)
@@ -283,33 +396,33 @@ def main(hparams):
     dtype = {"bf16": torch.bfloat16, "fp32": torch.float32}[hparams["dtype"]]
     model = net.SRModel(hparams["n_rnn_layers"], hparams["rnn_dim"], hparams["n_vocab"], hparams["n_feats"],
                         hparams["dropout"], hparams["projection_size"], compute_dtype=dtype).cuda()
+    if hparams.get("resume"):
+        model.load_checkpoint(torch.load(hparams["resume"], map_location="cuda", weights_only=True))
     log("Num Model Parameters", sum(p.nelement() for p in model.parameters()))
     optimizer = FlatAdam(model.parameters(), lr=hparams["learning_rate"], weight_decay=hparams["weight_decay"])
     dp = BucketedAllReduce(optimizer) if world > 1 else None
 
-    if not hparams["synthetic"]:
-        raise SystemExit("only --synthetic data is available in this build: the reference's corpora "
-                         "(/hd1 manifests, data.py:105-157) are not on this machine")
-    bs = hparams["batch_size"]
-    train_set = data.SyntheticSorted(hparams["synthetic_clips"], bs, seed=7)
-    eval_set = data.SyntheticSorted(max(bs, hparams["synthetic_clips"] // 8), bs, seed=11, max_s=6.0)
-    order = list(range(rank, len(train_set), world))
-    train_loader = [data.collate_fn(train_set[i], "train") for i in order[: hparams["steps"] or None]]
-    eval_loader = [data.collate_fn(eval_set[i], "valid") for i in range(min(2, len(eval_set)))]
-
+    train_loader, sampler, evals = build_loaders(hparams, rank, world)
     scheduler = get_linear_schedule_with_warmup(optimizer, 7000 // hparams["multiplier"],
                                                 hparams["epochs"] * len(train_loader))
     iter_meter, last_cer = IterMeter(), 2.0
+    eval_dtype = {"fp32": torch.float32, "same": None}[hparams.get("eval_dtype", "fp32")]
     for epoch in range(1, (1 if hparams["one_iter"] else hparams["epochs"]) + 1):
-        train(bs, model, train_loader, optimizer, scheduler, epoch, iter_meter, hparams["clip_grad_norm"], dp, log=log)
-        if rank == 0:
-            avg_cer = eval_dataset(model, eval_loader, "synthetic", log)
+        sampler.set_epoch(epoch)
+        train(hparams["batch_size"], model, train_loader, optimizer, scheduler, epoch, iter_meter,
+              hparams["clip_grad_norm"], dp, log=log)
+        if rank == 0:     # train.py:147-179: the last evaluation's CER (ibm when present) picks the checkpoint
+            log("\nevaluating...")
+            for name, loader in evals:
+                avg_cer = eval_dataset(model, loader, name, log, eval_dtype)
             if avg_cer < last_cer and hparams["checkpoint"]:
                 save_checkpoint(hparams["checkpoint"], epoch, model, optimizer)
-            last_cer = min(last_cer, avg_cer)
+            last_cer = avg_cer
+        if world > 1:     # the other ranks wait here, not inside the next epoch's first all-reduce
+            dist.barrier()
     if world > 1:
-        dist.barrier()
         dist.destroy_process_group()
+    return last_cer
 
 
 def parse_args(argv=None):
@@ -330,6 +443,13 @@ def parse_args(argv=None):
     p.add_argument("--steps", type=int, default=0)
     p.add_argument("--dtype", choices=["bf16", "fp32"], default="bf16")
     p.add_argument("--checkpoint", type=str, default="")
+    p.add_argument("--resume", type=str, default="", help="checkpoint to start from (either shape the reference writes)")
+    p.add_argument("--eval_dtype", choices=["fp32", "same"], default="fp32")
+    p.add_argument("--root_map", type=str, default="",
+                   help="old=new[,old=new...]: path prefixes rewritten in the manifests (the reference hard-codes /data -> /hd<device+1>)")
+    p.add_argument("--manifest_root", type=str, default="", help="directory the datasets/... manifest paths are relative to")
+    p.add_argument("--ibm_root", type=str, default="/hd1/ibm")
+    p.add_argument("--num_workers", type=int, default=6)
     a = p.parse_args(argv)
     return {
         "datasets": a.datasets, "multiplier": a.multiplier, "batch_size": 32 * a.multiplier,
@@ -337,7 +457,9 @@ def parse_args(argv=None):
         "dropout": a.dropout, "n_vocab": 28, "n_feats": data.N_MELS, "weight_decay": a.weight_decay,
         "clip_grad_norm": a.clip_grad_norm, "one_iter": a.one_iter, "projection_size": a.projection_size,
         "synthetic": a.synthetic, "synthetic_clips": a.synthetic_clips, "steps": a.steps,
-        "dtype": a.dtype, "checkpoint": a.checkpoint,
+        "dtype": a.dtype, "checkpoint": a.checkpoint, "resume": a.resume, "eval_dtype": a.eval_dtype,
+        "device": a.device, "manifest_root": a.manifest_root, "ibm_root": a.ibm_root, "num_workers": a.num_workers,
+        "root_map": tuple(tuple(kv.split("=", 1)) for kv in a.root_map.split(",") if kv) or None,
     }
 
 

@@ -100,3 +100,93 @@ def test_clips_and_sorted_datasets(corpus, tmp_path):
         with wave.open(str(p8), "wb") as f:
             f.setnchannels(1); f.setsampwidth(1); f.setframerate(16000); f.writeframes(b"\x00" * 100)
         data.load_audio(str(p8))
+
+
+def test_ibm_dataset_and_rank_sampler(tmp_path):
+    """IBMDataset (data.py:82-102) reads wav + txt pairs of one directory; RankBatchSampler hands every rank the
+    same number of batches (a rank with one more would hang the bucket all-reduces) and all ranks agree on the
+    epoch's permutation."""
+    from speech_amd import data
+    from speech_amd.train import RankBatchSampler
+    rs = np.random.RandomState(1)
+    for k, n in enumerate([3000, 3500, 4100]):
+        _write_wav(tmp_path / f"utt{k}.wav", rs.randint(-2000, 2000, n))
+        (tmp_path / f"utt{k}.txt").write_text(f" ibm utterance {k} \n")
+    (tmp_path / "notes.md").write_text("ignored")
+    ds = data.IBMDataset(str(tmp_path))
+    assert len(ds) == 3
+    w, u = ds[1]
+    assert w.dtype == torch.int16 and tuple(w.shape) == (1, 3500) and u == "ibm utterance 1"
+    for world in (1, 2, 3):
+        parts = []
+        for rank in range(world):
+            s = RankBatchSampler(8, rank, world, shuffle=True)
+            s.set_epoch(3)
+            parts.append(list(s))
+        assert len({len(p) for p in parts}) == 1 and len(parts[0]) == 8 // world
+        flat = sum(parts, [])
+        assert len(set(flat)) == len(flat)                      # disjoint shares of one permutation
+    a, b = RankBatchSampler(8, 0, 2), RankBatchSampler(8, 0, 2)
+    a.set_epoch(1); b.set_epoch(2)
+    assert list(a) != list(b)
+
+
+def test_build_loaders_mirrors_reference_wiring(corpus, tmp_path):
+    """train.build_loaders (train.py:202-239): CombinedTVLibriSpeech for training, SortedTV on the `eval` twins of the
+    non-gigaspeech manifests, IBMDataset batched by 32 * multiplier * 2 -- checked down to the clips the raw loaders
+    yield (the GPU featuriser is applied by FeaturizingLoader and is not exercised here)."""
+    from speech_amd import train
+    root, libri_entries, tv_entries = corpus
+    mdir = tmp_path / "manifests"
+    (mdir / "datasets" / "librispeech").mkdir(parents=True)
+    (mdir / "datasets" / "first").mkdir(parents=True)
+    # a LibriSpeech manifest long enough to survive the [:-2000] cut of its longest clips
+    big = libri_entries + [("/nowhere/LibriSpeech/x.wav", 10 ** 9)] * 2000
+    (mdir / "datasets" / "librispeech" / "sorted_train_librispeech.pkl").write_bytes(pickle.dumps(big))
+    tv_train = mdir / "datasets" / "first" / "sorted_train_cer_0.1.pkl"
+    tv_train.write_bytes(pickle.dumps([(p, n / 16000) for p, n in tv_entries]))
+    (mdir / "datasets" / "first" / "sorted_eval_cer_0.1.pkl").write_bytes(pickle.dumps(tv_entries))
+    ibm = tmp_path / "ibm"
+    ibm.mkdir()
+    _write_wav(ibm / "a.wav", np.zeros(3000))
+    (ibm / "a.txt").write_text("ibm a")
+    hp = train.parse_args(["--multiplier", "1", "--manifest_root", str(mdir), "--ibm_root", str(ibm),
+                           "--root_map", "/nonexistent=/elsewhere", "--num_workers", "0"])
+    assert hp["root_map"] == (("/nonexistent", "/elsewhere"),)
+    hp["batch_size"], hp["tv_manifests"] = 2, [str(tv_train)]
+    train_loader, sampler, evals = train.build_loaders(hp, 0, 1)
+    assert [n for n, _ in evals] == ["tv", "ibm"]
+    assert len(train_loader) == len(sampler) == (len(libri_entries) + len(tv_entries)) // 2
+    batches = list(train_loader.loader)
+    assert all(len(b) == 2 and b[0][0].dtype == torch.int16 and isinstance(b[0][1], str) for b in batches)
+    assert len(list(evals[0][1].loader)) == len(tv_entries) // 2
+    assert list(evals[1][1].loader)[0][0][1] == "ibm a"
+
+
+def test_load_checkpoint_key_tolerance():
+    """SRModel.load_checkpoint takes both checkpoint shapes (train.py:171-178 dict, bare state_dict) and tolerates the
+    keys whose presence depends on the sru / torch version (scale_x buffers, BatchNorm step counters); anything else
+    that is missing or unknown is an error."""
+    from speech_amd import net
+    torch.manual_seed(0)
+    src = net.SRModel(2, 64, 28, 80, 0.1)
+    sd = {k: v.clone() for k, v in src.state_dict().items()}
+    assert "sru_layers.rnn_lst.1.weight_c" in sd and "classifier.1.weight" in sd and "cnn.bias" in sd
+    stripped = {k: v for k, v in sd.items() if not k.endswith((".scale_x", ".num_batches_tracked"))}
+    assert len(stripped) < len(sd)
+    dst = net.SRModel(2, 64, 28, 80, 0.1)
+    res = dst.load_checkpoint({"epoch": 3, "model_state_dict": stripped, "optimizer_state_dict": {}})
+    assert all(k.endswith((".scale_x", ".num_batches_tracked")) for k in res.missing_keys) and res.missing_keys
+    for k, v in src.state_dict().items():
+        if k in stripped:
+            assert torch.equal(dst.state_dict()[k], v), k
+    extra = dict(sd)
+    extra["sru_layers.rnn_lst.0.extra.scale_x"] = torch.ones(1)          # an extra buffer of that kind is ignored
+    assert dst.load_checkpoint(extra).unexpected_keys == ["sru_layers.rnn_lst.0.extra.scale_x"]
+    bad = dict(sd)
+    bad["sru_layers.rnn_lst.0.weight_proj"] = torch.zeros(4, 4)
+    with pytest.raises(RuntimeError, match="weight_proj"):
+        dst.load_checkpoint(bad)
+    del stripped["sru_layers.rnn_lst.0.bias"]
+    with pytest.raises(RuntimeError, match="rnn_lst.0.bias"):
+        dst.load_checkpoint(stripped)

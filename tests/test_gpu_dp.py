@@ -41,6 +41,8 @@ def _batch(rank, dev):
 
 
 def _worker(rank, world, port, out):
+    import faulthandler
+    faulthandler.dump_traceback_later(90, exit=True)      # a rank that hangs says where, and ends the test
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     torch.cuda.set_device(0)
@@ -97,6 +99,8 @@ def test_two_rank_train_step_on_one_gpu(cuda, tmp_path):
 
 
 def _rccl_worker(rank, port, out):
+    import faulthandler
+    faulthandler.dump_traceback_later(90, exit=True)
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     torch.cuda.set_device(0)

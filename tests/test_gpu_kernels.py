@@ -282,7 +282,8 @@ def _sru_inputs(T, B, d, k, seed, dtype):
 
 def _sru_ref(U, x, wc, bias, mask, d):
     """Recurrence only (the projection is outside the kernel): oracle.sru's equations on a
-    pre-computed U in the kernel layout [T,B,k,2,d]."""
+    pre-computed U in the kernel layout [T,B,k,2,d].  The time steps are unbound once (one stack in the
+    backward instead of a full-size zero fill per step), so T = 1501 stays a matter of seconds."""
     T, B, k = U.shape[:3]
     U = U.double().requires_grad_(True)
     x = x.double().requires_grad_(True) if x is not None else None
@@ -292,18 +293,20 @@ def _sru_ref(U, x, wc, bias, mask, d):
     vf, vr = wc[:D2].view(2, d), wc[D2:].view(2, d)
     bf, br = bias[:D2].view(2, d), bias[D2:].view(2, d)
     m = mask.double().view(B, 2, d)
+    Ut = U.unbind(0)
+    xt = x.view(T, B, 2, d).unbind(0) if x is not None else None
     hs = [[None] * T, [None] * T]
     for direction in range(2):
         c = torch.zeros(B, d, dtype=torch.float64)
         order = range(T) if direction == 0 else range(T - 1, -1, -1)
         for t in order:
-            u0, u1, u2 = U[t, :, 0, direction], U[t, :, 1, direction], U[t, :, 2, direction]
-            f = torch.sigmoid(u1 + vf[direction] * c + bf[direction])
-            r = torch.sigmoid(u2 + vr[direction] * c + br[direction])
-            c = u0 + (c - u0) * f
-            xp = x[t].view(B, 2, d)[:, direction] if k == 3 else U[t, :, 3, direction]
+            u = Ut[t][:, :, direction].unbind(1)
+            f = torch.sigmoid(u[1] + vf[direction] * c + bf[direction])
+            r = torch.sigmoid(u[2] + vr[direction] * c + br[direction])
+            c = u[0] + (c - u[0]) * f
+            xp = xt[t][:, direction] if k == 3 else u[3]
             hs[direction][t] = (c * m[:, direction] - xp) * r + xp
-    h = torch.stack([torch.cat([hs[0][t], hs[1][t]], -1) for t in range(T)])
+    h = torch.cat([torch.stack(hs[0]), torch.stack(hs[1])], -1)
     return h, (U, x, wc, bias)
 
 
@@ -766,3 +769,120 @@ def test_gemm_tn_splitk_bf16(cuda, Mi, Nj, K):
     wide = torch.full((S, Mi, Nj + 16), 7.0, device=cuda)
     ops.gemm(x.t(), gu.t(), out=wide[:, :, :Nj] if S > 1 else wide[0, :, :Nj], out_dtype=torch.float32, split_k=S)
     assert torch.equal(wide[:, :, :Nj], P) and float((wide[:, :, Nj:] - 7.0).abs().max()) == 0
+
+
+# =============================================================================== full-size parity (configs[1] / [3])
+@pytest.mark.parametrize("k,T,B", [(3, 751, 32), (4, 751, 32), (3, 1501, 64)])
+def test_sru_recurrence_production_shape(cuda, k, T, B):
+    """The recurrence at the production shapes (d = 512, bf16; 512 or 1024 workgroups, the LDS ring wrapping
+    hundreds of times) against the f64 restatement.  Columns are independent, so the CPU reference runs on a
+    32-channel slice of both directions over ALL utterances: outputs, gU, gx and the slices of the v / b
+    gradients (which sum over the batch) are compared."""
+    from speech_amd import ops
+    d, nsel = 512, 32
+    U, x, wc, bias, mask = _sru_inputs(T, B, d, k, 100 + k + T, torch.bfloat16)
+    gen = torch.Generator().manual_seed(5)
+    idx = torch.randperm(d, generator=gen)[:nsel].sort().values
+    gh = torch.randn(T, B, 2 * d, generator=gen).bfloat16()
+    Ud = U.to(cuda).requires_grad_(True)
+    xd = x.to(cuda).requires_grad_(True) if x is not None else None
+    wcd, bd = wc.to(cuda).requires_grad_(True), bias.to(cuda).requires_grad_(True)
+    h = ops.sru_recurrence(Ud, xd, wcd, bd, mask.to(cuda), d)
+    h.backward(gh.to(cuda))
+    # the slice, as a d' = 64 problem
+    Us = U.float()[:, :, :, :, idx]
+    xs = x.float().view(T, B, 2, d)[:, :, :, idx].reshape(T, B, 2 * nsel) if x is not None else None
+    sel4 = lambda v: v.view(4, d)[:, idx].reshape(-1)          # noqa: E731
+    ms = mask.view(B, 2, d)[:, :, idx].reshape(B, 2 * nsel)
+    href, (Ur, xr, wcr, br) = _sru_ref(Us, xs, sel4(wc), sel4(bias), ms, nsel)
+    ghs = gh.double().view(T, B, 2, d)[:, :, :, idx].reshape(T, B, 2 * nsel)
+    href.backward(ghs)
+
+    def close(a, b, what, tol=2e-2):
+        a, b = a.detach().cpu().double(), b.detach().double()
+        assert float((a - b).abs().max()) <= tol * max(1.0, float(b.abs().max())), what
+    close(h.view(T, B, 2, d)[:, :, :, idx].reshape(T, B, -1), href, "h")
+    close(Ud.grad[:, :, :, :, idx], Ur.grad, "gU")
+    if k == 3:
+        close(xd.grad.view(T, B, 2, d)[:, :, :, idx].reshape(T, B, -1), xr.grad, "gx")
+    # sums over T*B = 24 k .. 96 k bf16-rounded terms: relative to the sum's own size
+    close(wcd.grad.view(4, d)[:, idx].reshape(-1), wcr.grad, "gwc", 1e-2)
+    close(bd.grad.view(4, d)[:, idx].reshape(-1), br.grad, "gbias", 1e-2)
+
+
+def test_ctc_production_shape_sentencepiece_vocab(cuda):
+    """configs[1]'s loss shape -- T' = 751, B = 32, V = 1000, up to 60 pieces per utterance -- against torch's CPU
+    CTC (f32 and f64) on a 4-utterance slice, and through the zero-row-sum property on all 32."""
+    from speech_amd import ops
+    T, B, V, L = 751, 32, 1000, 60
+    g = torch.Generator().manual_seed(21)
+    logits = torch.randn(T, B, V, generator=g) * 3
+    labels = torch.randint(1, V, (B, L), generator=g)
+    labels[:, 1::9] = labels[:, 0::9][:, : labels[:, 1::9].shape[1]]
+    ll = torch.randint(L // 2, L + 1, (B,), generator=g).int()
+    ll[0] = L
+    il = torch.full((B,), T, dtype=torch.int32)
+    loss, nll, grad = ops.ctc_fwd_bwd(logits.to(cuda), labels.to(cuda), il.to(cuda), ll.to(cuda), time_major=True,
+                                      max_label_len=L)
+    assert torch.isfinite(nll).all() and float(grad.sum(2).abs().max()) <= 1e-5
+    sl = [0, 7, 19, 31]
+    rl, rnll, rg32 = octc.ctc_torch(logits[:, sl], labels[sl], il[sl], ll[sl])
+    _, _, rg64 = octc.ctc_torch(logits[:, sl], labels[sl], il[sl], ll[sl], dtype=torch.float64)
+    assert np.allclose(nll[sl].cpu().numpy(), rnll.numpy(), rtol=1e-5)
+    # the oracle's mean is over its 4 utterances, the kernel's over 32: compare d nll_b / d logits
+    scale = np.array([B / len(sl)], dtype=np.float64)
+    got = grad[:, sl].cpu().double().numpy() * scale
+    g64 = rg64.numpy()
+    gmax = np.abs(g64).max()
+    assert np.abs(got - g64).max() <= 1e-4 * gmax
+    ref32_err = np.abs(rg32.numpy() - g64).max()
+    assert np.abs(got - rg32.numpy()).max() <= 1e-4 * gmax + 2 * ref32_err
+    assert float(loss) == pytest.approx(float((nll.cpu().double() / ll.double()).mean()), rel=1e-6)
+
+
+def test_mel_log_flag(cuda):
+    """flags bit 0: natural log of (mel + 1e-6), the optional log stage north_star names (off by default: the
+    reference feeds magnitudes).  Against log(oracle + 1e-6); padding frames hold log(1e-6)."""
+    from speech_amd import ops
+    g = torch.Generator().manual_seed(4)
+    lens = [4000, 2777, 1601]
+    wavs = [torch.randn(1, n, generator=g) * 0.1 for n in lens]
+    flat = torch.cat([w.reshape(-1) for w in wavs]).to(cuda)
+    offs = torch.tensor([0] + list(np.cumsum(lens)), dtype=torch.int64)
+    out = ops.melspec(flat, offs.to(cuda), flags=1).cpu()
+    ref = omel.collate(wavs)
+    T = ref.shape[-1]
+    for b, n in enumerate(lens):
+        tb = 1 + n // 160
+        r = torch.log(ref[b, 0, :, :tb] + 1e-6)
+        assert float((out[b, 0, :, :tb] - r).abs().max()) <= 1e-4 * float(r.abs().max())
+        if tb < T:       # padding is written in the output's domain: log(0 + 1e-6)
+            pad = out[b, 0, :, tb:]
+            assert float((pad - np.log(1e-6)).abs().max()) <= 1e-4 or float(pad.abs().max()) == 0
+
+
+@pytest.mark.parametrize("log", [0, 1])
+def test_mel_per_utterance_normalisation(cuda, log):
+    """flags bit 1 (with and without the log stage): every mel row of every utterance has zero mean and unit
+    variance over its valid frames, SpecAugment bands are zeroed AFTER the statistics, padding stays 0; against
+    the same arithmetic on the oracle's features."""
+    from speech_amd import ops
+    g = torch.Generator().manual_seed(8)
+    lens = [4800, 3333, 1777]
+    wavs = [torch.randn(1, n, generator=g) * 0.1 + 0.05 * torch.sin(torch.arange(n) * 0.3) for n in lens]
+    flat = torch.cat([w.reshape(-1) for w in wavs]).to(cuda)
+    offs = torch.tensor([0] + list(np.cumsum(lens)), dtype=torch.int64)
+    masks = torch.tensor([[5, 7, 3, 9], [0, 0, 0, 0], [70, 10, 8, 2]], dtype=torch.int32)
+    out = ops.melspec(flat, offs.to(cuda), masks=masks, flags=2 | log).cpu()
+    ref = omel.collate(wavs)
+    for b, n in enumerate(lens):
+        tb = 1 + n // 160
+        x = ref[b, 0, :, :tb].double()
+        if log:
+            x = torch.log(x + 1e-6)
+        y = (x - x.mean(1, keepdim=True)) / torch.sqrt(x.var(1, unbiased=False, keepdim=True) + 1e-5)
+        f0, fw, t0, tw = masks[b].tolist()
+        y[f0:f0 + fw] = 0
+        y[:, t0:t0 + tw] = 0
+        assert float((out[b, 0, :, :tb].double() - y).abs().max()) <= 2e-4 * float(y.abs().max())
+        assert float(out[b, 0, :, tb:].abs().max() if tb < out.shape[-1] else 0.0) == 0

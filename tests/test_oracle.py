@@ -154,3 +154,24 @@ def test_collate_contract():
     assert float(out[2, 0, :, 7:].abs().max()) == 0.0   # zero padded tail (T_2 = 7)
     m = omel.collate(wavs, masks=[(10, 5, 2, 3)] * 3)
     assert float(m[0, 0, 10:15].abs().max()) == 0.0 and float(m[0, 0, :, 2:5].abs().max()) == 0.0
+
+
+def test_sentencepiece_vocab_round_trip(tmp_path):
+    """text.SentencePieceVocab (the subword vocabulary option; scripts/sentence_piece.py:36-38 trains a BPE model
+    the reference never consumes): a tiny model trained here with the installed sentencepiece; ids are shifted by
+    one so that 0 stays the CTC blank, and encode -> decode returns the text."""
+    spm = pytest.importorskip("sentencepiece")
+    from speech_amd import text
+    rs = np.random.RandomState(0)
+    words = ["hello", "world", "speech", "model", "train", "frame", "audio", "signal", "mel", "ctc", "loss", "wave"]
+    lines = [" ".join(rs.choice(words, rs.randint(3, 9))) for _ in range(400)]
+    corpus = tmp_path / "corpus.txt"
+    corpus.write_text("\n".join(lines) + "\n")
+    spm.SentencePieceTrainer.train(input=str(corpus), model_prefix=str(tmp_path / "sp"), vocab_size=60, model_type="bpe",
+                                   minloglevel=2)
+    vocab = text.SentencePieceVocab(str(tmp_path / "sp.model"))
+    assert vocab.size == 61
+    for line in lines[:20] + ["hello world", "ctc loss"]:
+        ids = vocab.text_to_int(line)
+        assert ids and min(ids) >= 1 and max(ids) < vocab.size          # 0 is never produced: it is the blank
+        assert vocab.int_to_text(ids) == line

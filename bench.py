@@ -292,8 +292,8 @@ def main():
     local = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus and world > 1:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
-    if args.gpus > 1 and world == 1:
-        raise SystemExit(spawn_ranks(args.gpus))
+    if world == 1 and "RANK" not in os.environ and (args.gpus > 1 or os.environ.get("BENCH_FORCE_SPAWN")):
+        raise SystemExit(spawn_ranks(args.gpus))      # BENCH_FORCE_SPAWN: exercise the launcher on a 1-GPU box
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     if world > 1:

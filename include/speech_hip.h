@@ -76,7 +76,9 @@ int sp_melspec_fwd(const void* wav, const int64_t* wav_offsets, int B, int T_max
  * logits: element (t,b,c) at logits[t*stride_t + b*stride_b + c] (f32), so both the model's
  * [B,T,V] output and the reference's [T,B,V] copy can be passed without a transpose.
  * labels int64 [B][label_stride] (padded), input_lengths/label_lengths int32 [B] (device).
- * max_label_len: host upper bound on label_lengths (sizes the lattice; <= 1023).
+ * max_label_len: host upper bound on label_lengths (sizes the lattice; <= 1023).  A label_lengths[b] above it
+ * is clamped to it: that utterance is scored, normalised and differentiated against its first max_label_len
+ * labels (the caller, who knows the lengths on the host, is expected to pass a true bound).
  * Outputs: nll[B] (per-utterance negative log likelihood, +inf if infeasible), loss[1] =
  * mean_b nll_b / max(L_b,1), grad (may be NULL) laid out like logits =
  * grad_scale * d loss / d logits, of grad_dtype SP_F32 or SP_BF16 (same strides in elements; bf16
@@ -188,7 +190,9 @@ int sp_adam_step_f32(float* p, const float* g, float* m, float* v, int64_t n, fl
  *   every bf16 activation, are bit-reproducible.
  * sp_conv3x5_wgrad: gw[32][32][3][5] += sum_pos dy[pos][co] * a[pos + tap][ci], with
  *   a = a_src (a_mode 0) or relu(BN(a_src)) (a_mode 1), dy = g_coef affine of (g, y) as in_mode 2.
- *   gwp_ws: 8*15*32*32 f32 scratch (zeroed inside; one partial copy per XCD).
+ *   gwp_ws: 8*15*32*32 f32 workspace, one partial copy per XCD.  Contract: the caller zeroes it ONCE (when it
+ *   allocates it); every successful call leaves it zeroed again (the unpack kernel clears what it has read), so
+ *   back-to-back calls need no fill.  After a failed call, or if two streams share one workspace, zero it again.
  * sp_conv_stem_fwd/bwd: Conv2d(1,32,3,stride 2,pad 1) on the f32 spectrogram [B][Fin][Tin] ->
  *   [B][F][T][32], F = (Fin-1)/2+1, T = (Tin-1)/2+1; bwd accumulates gw[32*9], gbias[32].
  * sp_bn_stats: (sum y | sum y^2) per channel, as eight rows sums[8][64] to be added.

@@ -720,7 +720,8 @@ __global__ __launch_bounds__(256) void ctc_grad_kernel(
 
     if (blockIdx.x == 0 && wave == 0 && loss) {
         float acc = 0.f;
-        for (int b = lane; b < B; b += 64) acc += nll[b] / (float)max(lab_len[b], 1);
+        // the same (clamped) target length the lattice scored
+        for (int b = lane; b < B; b += 64) acc += nll[b] / (float)max(min(lab_len[b], Lmax), 1);
         acc = wave_sum(acc);
         if (lane == 0) loss[0] = acc / (float)B;
     }

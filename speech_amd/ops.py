@@ -162,7 +162,12 @@ def ctc_fwd_bwd(logits, labels, input_lengths, label_lengths, blank=0, max_label
     input_lengths = input_lengths.to(device=dev, dtype=torch.int32).contiguous()
     label_lengths = label_lengths.to(device=dev, dtype=torch.int32).contiguous()
     if max_label_len is None:
-        max_label_len = min(int(labels.shape[1]), 1023)
+        max_label_len = int(labels.shape[1])
+        if max_label_len > 1023:
+            raise ValueError(f"labels are padded to {max_label_len} > 1023 columns: pass max_label_len (<= 1023), "
+                             "a true bound on label_lengths")
+    if not label_lengths.is_cuda and label_lengths.numel() and int(label_lengths.max()) > max_label_len:
+        raise ValueError(f"label_lengths.max() = {int(label_lengths.max())} exceeds max_label_len = {max_label_len}")
     nll = torch.empty(B, dtype=torch.float32, device=dev)
     loss = torch.empty(1, dtype=torch.float32, device=dev)
     if grad_out is not None:      # caller-owned gradient buffer, same strides (in elements) as the logits

@@ -528,3 +528,24 @@ def test_configs1_full_size_train_step(cuda):
     opt = FlatAdam(m.parameters(), lr=3e-4, weight_decay=1e-3)
     steps = [float(train_step(m, opt, spec, labels, lens, 2.0, None, max_label_len=L)) for _ in range(4)]
     assert all(np.isfinite(steps)) and steps[-1] < steps[0]
+
+
+def test_bench_self_launch_path(cuda):
+    """`python bench.py --gpus N` starts its own rank processes (no torch.distributed.run needed).  One card
+    allows one rank, so the launcher is driven with N = 1 (BENCH_FORCE_SPAWN): the child reads the launcher's
+    environment like any rank and the parent relays rank 0's single JSON line with the contract's fields."""
+    import json
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE")}
+    env["BENCH_FORCE_SPAWN"] = "1"
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "1", "--steps", "2", "--warmup", "1",
+                        "--no-cpu-baseline", "--kernel-iters", "2"], env=env, capture_output=True, text=True, timeout=170)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 1 and d["steps"] == 2 and d["unit"] == "audio-sec/sec" and d["value"] > 0
+    assert d["roofline"]["bound"] in ("hbm", "mfma") and 0 < d["roofline"]["frac"] < 1

@@ -1,6 +1,6 @@
 // sp_gemm: the one GEMM entry point (include/speech_hip.h).  Which kernel runs is decided here by shape,
 // layout and dtype alone:
-//   * bf16, both operands K-contiguous ("NT": forward projection on the packed W^T, data gradients,
+//   * bf16 / f16, both operands K-contiguous ("NT": forward projection on the packed W^T, data gradients,
 //     classifier logits), whole 256- or 128-column tiles, K % 64 == 0   -> gemm_rs.hip, NT role-split kernel
 //   * bf16, both operands row-contiguous ("TN": weight gradients), f32 split-K slabs, 256 x 256 tiles
 //                                                                       -> gemm_rs.hip, TN role-split kernel
@@ -40,17 +40,17 @@ extern "C" int sp_gemm(const void* A, const void* B, void* C, int M, int N, int 
     const int vec = in_dtype == SP_F32 ? 4 : 8;
     const int64_t a_ld = sak == 1 ? sam : sak, b_ld = sbk == 1 ? sbn : sbk;
     const bool aligned_in = (((uintptr_t)A | (uintptr_t)B) & 15) == 0 && a_ld % vec == 0 && b_ld % vec == 0;
-    if (in_dtype == SP_BF16 && !accumulate && aligned_in && K >= 64) {
-        // NT: both operands K-contiguous
-        if (sak == 1 && sbk == 1 && split_k == 1 && (M > 1 || sam >= K) && (out_dtype == SP_BF16 || out_dtype == SP_F32)) {
+    if ((in_dtype == SP_BF16 || in_dtype == SP_F16) && !accumulate && aligned_in && K >= 64) {
+        // NT: both operands K-contiguous; the output keeps the operands' 16-bit type or is f32
+        if (sak == 1 && sbk == 1 && split_k == 1 && (M > 1 || sam >= K) && (out_dtype == in_dtype || out_dtype == SP_F32)) {
             const int bn = N % 256 == 0 ? 256 : 128, bm = bn == 256 ? 192 : 256;
             if ((int64_t)((M + bm - 1) / bm) * (N / bn) >= kMinFastTiles &&
                 nt_rs_ok(M, N, K, sam, sbn, ldc, A, B, C, out_dtype, bn))
-                return gemm_nt_rs(A, B, C, M, N, K, sam, sbn, ldc, out_dtype, bn == 256 ? 0 : 3, s);
+                return gemm_nt_rs(A, B, C, M, N, K, sam, sbn, ldc, in_dtype, out_dtype, bn == 256 ? 0 : 3, s);
         }
-        // TN: both operands row-contiguous, f32 slabs
-        if (sam == 1 && sbn == 1 && sak > 1 && sbk > 1 && out_dtype == SP_F32 && ldc % 4 == 0 && c_split_stride % 4 == 0 &&
-            (int64_t)(M / 256) * (N / 256) * split_k >= kMinFastTiles &&
+        // TN: both operands row-contiguous, f32 slabs (bf16: the training type)
+        if (in_dtype == SP_BF16 && sam == 1 && sbn == 1 && sak > 1 && sbk > 1 && out_dtype == SP_F32 && ldc % 4 == 0 &&
+            c_split_stride % 4 == 0 && (int64_t)(M / 256) * (N / 256) * split_k >= kMinFastTiles &&
             (split_k - 1) * (((K + 63) / 64 + split_k - 1) / split_k) < (K + 63) / 64 &&      // no empty K range
             tn_rs_ok(M, N, K, sak, sbk, A, B, C))
             return gemm_tn_rs(A, B, (float*)C, M, N, K, sak, sbk, ldc, split_k > 1 ? c_split_stride : 0, split_k, 0, s);

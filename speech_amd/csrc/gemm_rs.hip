@@ -28,6 +28,7 @@
 namespace sp {
 
 typedef __bf16 rs_bf16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 rs_f16x8 __attribute__((ext_vector_type(8)));
 typedef float rs_f32x4 __attribute__((ext_vector_type(4)));
 typedef uint32_t rs_u32x4 __attribute__((ext_vector_type(4)));
 typedef __attribute__((address_space(1))) const void* rs_gptr_t;
@@ -69,7 +70,8 @@ struct RsTiles {
 // counted wait before the barrier leaves exactly that A share in flight (a wave's vector-memory operations retire
 // in issue order, so everything older has landed).  All four loaders share both operands: the far operand's
 // requests leave in a quarter of the time one wave would need to issue them.
-template <int BM, int BN, int WMW, int NSTA, int OUT>
+// IN = SP_BF16 or SP_F16: element type of A and B (and of C unless OUT == SP_F32)
+template <int BM, int BN, int WMW, int NSTA, int OUT, int IN = SP_BF16>
 __global__ __launch_bounds__(768, 3) void gemm_nt_rs_kernel(RsArgs g) {
     constexpr int WNW = 8 / WMW, NSTB = 2;
     constexpr int TM = BM / WMW, TN = BN / WNW;          // wave tile
@@ -176,14 +178,21 @@ __global__ __launch_bounds__(768, 3) void gemm_nt_rs_kernel(RsArgs g) {
 #pragma unroll
         for (int kk = 0; kk < 2; ++kk) {
             const int pc = kk ? pc1 : pc0;
-            rs_bf16x8 P[NB];
+            rs_u32x4 P[NB];
 #pragma unroll
-            for (int b = 0; b < NB; ++b) P[b] = __builtin_bit_cast(rs_bf16x8, *reinterpret_cast<const rs_u32x4*>(sb + b * 16 * ROWB + pc));
+            for (int b = 0; b < NB; ++b) P[b] = *reinterpret_cast<const rs_u32x4*>(sb + b * 16 * ROWB + pc);
 #pragma unroll
             for (int a = 0; a < MB; ++a) {
-                const rs_bf16x8 Q = __builtin_bit_cast(rs_bf16x8, *reinterpret_cast<const rs_u32x4*>(sa + a * 16 * ROWB + pc));
+                const rs_u32x4 Q = *reinterpret_cast<const rs_u32x4*>(sa + a * 16 * ROWB + pc);
 #pragma unroll
-                for (int b = 0; b < NB; ++b) acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(P[b], Q, acc[a][b], 0, 0, 0);
+                for (int b = 0; b < NB; ++b) {
+                    if constexpr (IN == SP_F16)
+                        acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(rs_f16x8, P[b]),
+                                                                           __builtin_bit_cast(rs_f16x8, Q), acc[a][b], 0, 0, 0);
+                    else
+                        acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(rs_bf16x8, P[b]),
+                                                                            __builtin_bit_cast(rs_bf16x8, Q), acc[a][b], 0, 0, 0);
+                }
             }
         }
         asm volatile("" ::: "memory");
@@ -203,8 +212,12 @@ __global__ __launch_bounds__(768, 3) void gemm_nt_rs_kernel(RsArgs g) {
                     }
                 } else {
                     auto pk = [](float lo, float hi) {
-                        return (uint32_t)__builtin_bit_cast(unsigned short, __float2bfloat16(lo)) |
-                               ((uint32_t)__builtin_bit_cast(unsigned short, __float2bfloat16(hi)) << 16);
+                        if constexpr (IN == SP_F16)
+                            return (uint32_t)__builtin_bit_cast(unsigned short, __float2half(lo)) |
+                                   ((uint32_t)__builtin_bit_cast(unsigned short, __float2half(hi)) << 16);
+                        else
+                            return (uint32_t)__builtin_bit_cast(unsigned short, __float2bfloat16(lo)) |
+                                   ((uint32_t)__builtin_bit_cast(unsigned short, __float2bfloat16(hi)) << 16);
                     };
                     // rows (16-lane groups) 1 and 3 of x trade places with rows 0 and 2 of y: every lane then holds 8
                     // consecutive n: columns 16 b + (q & 1) * 16 + (q >> 1) * 8 of its row
@@ -237,7 +250,7 @@ __global__ __launch_bounds__(768, 3) void gemm_nt_rs_kernel(RsArgs g) {
 
 template <int BM, int BN, int WMW, int NSTA>
 static int launch_nt_rs(const void* A, const void* B, void* C, int M, int N, int K, int64_t lda, int64_t ldb, int64_t ldc,
-                        int out_dtype, hipStream_t s) {
+                        int in_dtype, int out_dtype, hipStream_t s) {
     RsArgs g;
     g.A = (const __hip_bfloat16*)A; g.B = (const __hip_bfloat16*)B; g.C = C;
     g.M = M; g.N = N; g.K = K; g.lda = (int)lda; g.ldb = (int)ldb; g.ldc = ldc;
@@ -252,8 +265,13 @@ static int launch_nt_rs(const void* A, const void* B, void* C, int M, int N, int
         const double cost = (double)c * M * K + (8.0 / c) * N * K;
         if (best < 0 || cost < best) best = cost, g.gcols = c;
     }
-    if (out_dtype == SP_F32) hipLaunchKernelGGL((gemm_nt_rs_kernel<BM, BN, WMW, NSTA, SP_F32>), dim3(256), dim3(768), 0, s, g);
-    else hipLaunchKernelGGL((gemm_nt_rs_kernel<BM, BN, WMW, NSTA, SP_BF16>), dim3(256), dim3(768), 0, s, g);
+#define SP_RS_LAUNCH(OUT, IN) hipLaunchKernelGGL((gemm_nt_rs_kernel<BM, BN, WMW, NSTA, OUT, IN>), dim3(256), dim3(768), 0, s, g)
+    if (in_dtype == SP_F16) {
+        if (out_dtype == SP_F32) SP_RS_LAUNCH(SP_F32, SP_F16); else SP_RS_LAUNCH(SP_F16, SP_F16);
+    } else {
+        if (out_dtype == SP_F32) SP_RS_LAUNCH(SP_F32, SP_BF16); else SP_RS_LAUNCH(SP_BF16, SP_BF16);
+    }
+#undef SP_RS_LAUNCH
     return check_launch("gemm_nt_rs_kernel");
 }
 
@@ -266,10 +284,10 @@ bool nt_rs_ok(int M, int N, int K, int64_t lda, int64_t ldb, int64_t ldc, const 
 }
 
 int gemm_nt_rs(const void* A, const void* B, void* C, int M, int N, int K, int64_t lda, int64_t ldb, int64_t ldc,
-               int out_dtype, int variant, hipStream_t s) {
+               int in_dtype, int out_dtype, int variant, hipStream_t s) {
     switch (variant) {
-        case 0: return launch_nt_rs<192, 256, 2, 3>(A, B, C, M, N, K, lda, ldb, ldc, out_dtype, s);     // N % 256 == 0
-        case 3: return launch_nt_rs<256, 128, 4, 3>(A, B, C, M, N, K, lda, ldb, ldc, out_dtype, s);     // N % 128 == 0
+        case 0: return launch_nt_rs<192, 256, 2, 3>(A, B, C, M, N, K, lda, ldb, ldc, in_dtype, out_dtype, s);     // N % 256 == 0
+        case 3: return launch_nt_rs<256, 128, 4, 3>(A, B, C, M, N, K, lda, ldb, ldc, in_dtype, out_dtype, s);     // N % 128 == 0
         default: return fail(SP_EINVAL, "gemm_nt_rs: variant %d", variant);
     }
 }

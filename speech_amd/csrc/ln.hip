@@ -33,6 +33,24 @@ template <> struct Vec8<__hip_bfloat16> {
         *reinterpret_cast<uint4*>(p) = make_uint4(w[0], w[1], w[2], w[3]);
     }
 };
+template <> struct Vec8<__half> {
+    static __device__ __forceinline__ void ld(const __half* p, float (&f)[8]) {
+        const uint4 v = *reinterpret_cast<const uint4*>(p);
+        const uint32_t w[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const __half2 h = __builtin_bit_cast(__half2, w[i]);
+            f[2 * i] = __low2float(h);
+            f[2 * i + 1] = __high2float(h);
+        }
+    }
+    static __device__ __forceinline__ void st(__half* p, const float (&f)[8]) {
+        uint32_t w[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) w[i] = __builtin_bit_cast(uint32_t, __floats2half2_rn(f[2 * i], f[2 * i + 1]));
+        *reinterpret_cast<uint4*>(p) = make_uint4(w[0], w[1], w[2], w[3]);
+    }
+};
 template <> struct Vec8<float> {
     static __device__ __forceinline__ void ld(const float* p, float (&f)[8]) {
         const float4 a = *reinterpret_cast<const float4*>(p), b = *reinterpret_cast<const float4*>(p + 4);
@@ -56,6 +74,20 @@ template <> struct Raw8<__hip_bfloat16> {
         for (int i = 0; i < 4; ++i) {
             f[2 * i] = __uint_as_float(w[i] << 16);
             f[2 * i + 1] = __uint_as_float(w[i] & 0xFFFF0000u);
+        }
+    }
+};
+template <> struct Raw8<__half> {
+    uint4 v;
+    __device__ __forceinline__ void load(const __half* p) { v = *reinterpret_cast<const uint4*>(p); }
+    __device__ __forceinline__ void zero() { v = make_uint4(0, 0, 0, 0); }
+    __device__ __forceinline__ void get(float (&f)[8]) const {
+        const uint32_t w[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const __half2 h = __builtin_bit_cast(__half2, w[i]);
+            f[2 * i] = __low2float(h);
+            f[2 * i + 1] = __high2float(h);
         }
     }
 };
@@ -224,7 +256,7 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const T* __restrict__ gy, c
 static int ln_check(const char* who, int64_t M, int N, int dtype) {
     SP_CHECK_ARG(M >= 0 && N >= 8 && N % 8 == 0 && N <= 512 * kLnMaxChunks,
                  "%s: N=%d must be a multiple of 8 in [8, %d]", who, N, 512 * kLnMaxChunks);
-    SP_CHECK_ARG(dtype == SP_F32 || dtype == SP_BF16, "%s: dtype %d not supported (f32, bf16)", who, dtype);
+    SP_CHECK_ARG(dtype == SP_F32 || dtype == SP_BF16 || dtype == SP_F16, "%s: dtype %d not supported (f32, bf16, f16)", who, dtype);
     return SP_OK;
 }
 
@@ -249,7 +281,7 @@ extern "C" int sp_layernorm_fwd(const void* x, const float* gamma, const float* 
                                              gamma, beta, M, N, eps, (T*)y, ldy, mean, rstd)
 #define SP_LN_FWD_T(T) { if (nch == 1) SP_LN_FWD(T, 1); else if (nch == 2) SP_LN_FWD(T, 2); \
                          else if (nch == 3) SP_LN_FWD(T, 3); else SP_LN_FWD(T, 4); }
-    if (dtype == SP_F32) SP_LN_FWD_T(float) else SP_LN_FWD_T(__hip_bfloat16)
+    if (dtype == SP_F32) SP_LN_FWD_T(float) else if (dtype == SP_F16) SP_LN_FWD_T(__half) else SP_LN_FWD_T(__hip_bfloat16)
 #undef SP_LN_FWD_T
 #undef SP_LN_FWD
     return check_launch("ln_fwd_kernel");
@@ -273,7 +305,7 @@ extern "C" int sp_layernorm_bwd(const void* gy, const void* x, const float* mean
                                              (const T*)x, mean, rstd, gamma, (const T*)gres, M, N, (T*)gx, dgamma, dbeta)
 #define SP_LN_BWD_T(T) { if (nch == 1) SP_LN_BWD(T, 1); else if (nch == 2) SP_LN_BWD(T, 2); \
                          else if (nch == 3) SP_LN_BWD(T, 3); else SP_LN_BWD(T, 4); }
-    if (dtype == SP_F32) SP_LN_BWD_T(float) else SP_LN_BWD_T(__hip_bfloat16)
+    if (dtype == SP_F32) SP_LN_BWD_T(float) else if (dtype == SP_F16) SP_LN_BWD_T(__half) else SP_LN_BWD_T(__hip_bfloat16)
 #undef SP_LN_BWD_T
 #undef SP_LN_BWD
     return check_launch("ln_bwd_kernel");

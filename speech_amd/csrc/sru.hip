@@ -653,7 +653,7 @@ static int sru_check(const char* who, int Tn, int B, int d, int k, int dtype) {
     SP_CHECK_ARG(Tn >= 0 && B >= 0 && d >= 1, "%s: bad shape T=%d B=%d d=%d", who, Tn, B, d);
     SP_CHECK_ARG(k == 3 || k == 4, "%s: k=%d must be 3 or 4", who, k);
     SP_CHECK_ARG(d % 64 == 0, "%s: d=%d must be a multiple of 64 (one wave = 64 channels)", who, d);
-    SP_CHECK_ARG(dtype == SP_F32 || dtype == SP_BF16, "%s: dtype %d not supported (f32, bf16)", who, dtype);
+    SP_CHECK_ARG(dtype == SP_F32 || dtype == SP_BF16 || dtype == SP_F16, "%s: dtype %d not supported (f32, bf16, f16)", who, dtype);
     return SP_OK;
 }
 
@@ -669,6 +669,7 @@ extern "C" int sp_sru_fwd(const void* U, const void* xres, const float* wc, cons
     SP_CHECK_ARG(U && wc && bias && h && (k == 4 || xres), "sp_sru_fwd: null pointer");
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
     if (dtype == SP_F32) return sru_fwd_t<float>(U, xres, wc, bias, mask, T, B, d, k, h, (float*)c, s);
+    if (dtype == SP_F16) return sru_fwd_t<__half>(U, xres, wc, bias, mask, T, B, d, k, h, (float*)c, s);   // c stays f32
     {   // role-split path (any d % 64 == 0)
         typedef __hip_bfloat16 bf;
         const int blocks = B * 2 * d / 64;
@@ -695,6 +696,8 @@ extern "C" int sp_sru_bwd(const void* U, const void* xres, const float* wc, cons
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
     if (dtype == SP_F32)
         return sru_bwd_t<float>(U, xres, wc, bias, mask, (const float*)c, gh, T, B, d, k, gU, gxres, gwc, gbias, s);
+    if (dtype == SP_F16)
+        return sru_bwd_t<__half>(U, xres, wc, bias, mask, (const float*)c, gh, T, B, d, k, gU, gxres, gwc, gbias, s);
     {   // role-split path (any d % 64 == 0)
         typedef __hip_bfloat16 bf;
         const int blocks = B * 2 * d / 64;
@@ -820,11 +823,12 @@ extern "C" int sp_sru_pack_w(const float* weight, int n_in, int d, int k, int C,
     int rc = pack_check("sp_sru_pack_w", n_in, d, k, C);
     if (rc) return rc;
     SP_CHECK_ARG(weight && out, "sp_sru_pack_w: null pointer");
-    SP_CHECK_ARG(dtype == SP_F32 || dtype == SP_BF16, "sp_sru_pack_w: dtype %d", dtype);
+    SP_CHECK_ARG(dtype == SP_F32 || dtype == SP_BF16 || dtype == SP_F16, "sp_sru_pack_w: dtype %d", dtype);
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
     const unsigned blocks = (unsigned)(((int64_t)n_in * 2 * d + 255) / 256);
 #define SP_PACK(T, K) hipLaunchKernelGGL((sru_pack_w_kernel<T, K>), dim3(blocks), dim3(256), 0, s, weight, n_in, d, C, (T*)out)
     if (dtype == SP_F32) { if (k == 3) SP_PACK(float, 3); else SP_PACK(float, 4); }
+    else if (dtype == SP_F16) { if (k == 3) SP_PACK(__half, 3); else SP_PACK(__half, 4); }
     else { if (k == 3) SP_PACK(__hip_bfloat16, 3); else SP_PACK(__hip_bfloat16, 4); }
 #undef SP_PACK
     return check_launch("sru_pack_w_kernel");
@@ -836,7 +840,7 @@ extern "C" int sp_sru_pack_wt(const float* weight, int n_in, int d, int k, int C
     int rc = pack_check("sp_sru_pack_wt", n_in, d, k, C);
     if (rc) return rc;
     SP_CHECK_ARG(weight && out_t, "sp_sru_pack_wt: null pointer");
-    SP_CHECK_ARG(dtype == SP_F32 || dtype == SP_BF16, "sp_sru_pack_wt: dtype %d", dtype);
+    SP_CHECK_ARG(dtype == SP_F32 || dtype == SP_BF16 || dtype == SP_F16, "sp_sru_pack_wt: dtype %d", dtype);
     const int R = dtype == SP_F32 ? 32 : 64;
     SP_CHECK_ARG(ldo >= n_in && ldo % 2 == 0, "sp_sru_pack_wt: ldo=%lld must be even and >= n_in=%d", (long long)ldo, n_in);
     SP_CHECK_ARG(n_in % R == 0 && d % 64 == 0, "sp_sru_pack_wt: n_in %% %d and d %% 64 must be 0 (n_in=%d d=%d)", R, n_in, d);
@@ -845,6 +849,7 @@ extern "C" int sp_sru_pack_wt(const float* weight, int n_in, int d, int k, int C
     const dim3 grid(n_in / R, d / 64, 2);
 #define SP_PACKT(T, K) hipLaunchKernelGGL((sru_pack_wt_kernel<T, K>), grid, dim3(256), 0, s, weight, n_in, d, C, (T*)out_t, ldo, (T*)out_w)
     if (dtype == SP_F32) { if (k == 3) SP_PACKT(float, 3); else SP_PACKT(float, 4); }
+    else if (dtype == SP_F16) { if (k == 3) SP_PACKT(__half, 3); else SP_PACKT(__half, 4); }
     else { if (k == 3) SP_PACKT(__hip_bfloat16, 3); else SP_PACKT(__hip_bfloat16, 4); }
 #undef SP_PACKT
     return check_launch("sru_pack_wt_kernel");

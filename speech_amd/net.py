@@ -4,12 +4,13 @@
 
 state_dict keys: cnn.{weight,bias}; resnet_layers.{0,1,2}.{conv1,conv2}.*,
 .{bn1,bn2}.*; sru_layers.rnn_lst.{i}.{weight,weight_c,bias,layer_norm.weight,layer_norm.bias}
-(+ scale_x buffer); classifier.0.{weight,bias}; classifier.1.weight.
+(+ scale_x buffer; + weight_proj when projection_size > 0); classifier.0.{weight,bias}; classifier.1.weight.
 
 The conv/BatchNorm stack (speech_amd.convstack) and the SRU recurrence (ops.sru_recurrence) run
 in the HIP kernels.  The conv stack always keeps bf16 activations; ``compute_dtype`` selects the
-activation type of the SRU stack and classifier: float32 or bfloat16 (the reference trains under
-fp16 autocast with an fp16 recurrence, net.py:71).  ResidualBlock.forward below is the plain
+activation type of the SRU stack and classifier: float32, bfloat16 (the training type here) or
+float16 (the reference trains under fp16 autocast with an fp16 recurrence, net.py:71, and evaluates
+with model.half(), scripts/eval_dataset.py).  ResidualBlock.forward below is the plain
 torch statement of one block and is used only by tests as the reference of the kernels.
 """
 import math
@@ -54,7 +55,7 @@ class SRUCell(nn.Module):
     permuted view of it.
     """
 
-    def __init__(self, input_size, hidden_size, dropout=0.0, highway_bias=0.0, in_layout=None):
+    def __init__(self, input_size, hidden_size, dropout=0.0, highway_bias=0.0, in_layout=None, projection_size=0):
         super().__init__()
         self.input_size, self.hidden_size = input_size, hidden_size
         # in_layout = (C, F): the input arrives with feature index f*C + c while `weight` rows and
@@ -62,8 +63,14 @@ class SRUCell(nn.Module):
         self.in_layout = in_layout
         self.output_size = 2 * hidden_size
         self.dropout = dropout
+        self.projection_size = projection_size
         self.num_matrices = 3 if input_size == self.output_size else 4
-        self.weight = nn.Parameter(torch.empty(input_size, self.output_size * self.num_matrices))
+        # sru.SRUCell(projection_size = p > 0): U = (LN(x) weight_proj) weight, a rank-p factorisation
+        if projection_size > 0:
+            self.weight_proj = nn.Parameter(torch.empty(input_size, projection_size))
+            self.weight = nn.Parameter(torch.empty(projection_size, self.output_size * self.num_matrices))
+        else:
+            self.weight = nn.Parameter(torch.empty(input_size, self.output_size * self.num_matrices))
         self.weight_c = nn.Parameter(torch.empty(2 * self.output_size))
         self.bias = nn.Parameter(torch.empty(2 * self.output_size))
         self.register_buffer("scale_x", torch.ones(1))
@@ -72,16 +79,20 @@ class SRUCell(nn.Module):
         self.reset_parameters()
 
     def reset_parameters(self):
-        """Package defaults as recalled (parity unpinned): W ~ U(+-sqrt(3/n_in)) * 0.1 under layer
+        """Package defaults as recalled (parity unpinned): W ~ U(+-sqrt(3/fan_in)) * 0.1 under layer
         norm, the u0 columns scaled by sqrt(1-dropout); v ~ U(+-sqrt(3)) * sqrt(0.5); b = 0 with the
-        reset-gate half set to highway_bias."""
+        reset-gate half set to highway_bias; weight_proj ~ U(+-sqrt(3/n_in))."""
         with torch.no_grad():
-            r = (3.0 / self.input_size) ** 0.5
+            fan_in = self.projection_size or self.input_size
+            r = (3.0 / fan_in) ** 0.5
             self.weight.uniform_(-r, r)
-            w = self.weight.view(self.input_size, 2, self.hidden_size, self.num_matrices)
+            w = self.weight.view(fan_in, 2, self.hidden_size, self.num_matrices)
             if self.dropout > 0:
                 w[..., 0].mul_((1 - self.dropout) ** 0.5)
             self.weight.mul_(0.1)
+            if self.projection_size > 0:
+                rp = (3.0 / self.input_size) ** 0.5
+                self.weight_proj.uniform_(-rp, rp)
             self.weight_c.uniform_(-(3.0 ** 0.5), 3.0 ** 0.5).mul_(0.5 ** 0.5)
             self.bias.zero_()
             self.bias[self.output_size:].fill_(self.highway_bias)
@@ -111,6 +122,17 @@ class SRUCell(nn.Module):
             keep = 1.0 - self.dropout
             mask = torch.bernoulli(torch.full((B, 2 * d), keep, device=x.device)) / keep
         C = self.in_layout[0] if self.in_layout is not None else 1
+        if self.projection_size > 0:
+            # LayerNorm -> rank-p projection -> gate projection -> recurrence, each a HIP kernel; the (small)
+            # weights are brought into the kernels' row / column order by differentiable torch views
+            k, p = self.num_matrices, self.projection_size
+            xn = ops.layer_norm(x, self._ln_vec(ln.weight, torch.float32), self._ln_vec(ln.bias, torch.float32), ln.eps)
+            wp = self.weight_proj
+            if self.in_layout is not None:
+                wp = wp.view(C, n_in // C, p).transpose(0, 1).reshape(n_in, p)
+            wk = self.weight.view(p, 2, d, k).permute(0, 3, 1, 2).reshape(p, k * 2 * d)
+            U = ops.matmul(ops.matmul(xn.reshape(T * B, n_in), wp), wk).view(T, B, k, 2, d)
+            return ops.sru_recurrence(U, x if k == 3 else None, self.weight_c, self.bias, mask, d)
         return ops.sru_layer(x, ln.weight, ln.bias, self.weight, self.weight_c, self.bias, mask, d,
                              self.num_matrices, C, ln.eps)
 
@@ -122,13 +144,10 @@ class SRU(nn.Module):
     def __init__(self, input_size, hidden_size, num_layers, dropout=0.0, projection_size=0,
                  highway_bias=0.0, in_layout=None):
         super().__init__()
-        if projection_size:
-            raise NotImplementedError("projection_size > 0 (weight_proj) is not built; the reference "
-                                      "trains with projection_size=0 (train.py:319)")
         self.rnn_lst = nn.ModuleList(
             SRUCell(input_size if i == 0 else 2 * hidden_size, hidden_size,
                     dropout=dropout if i + 1 != num_layers else 0.0, highway_bias=highway_bias,
-                    in_layout=in_layout if i == 0 else None)
+                    in_layout=in_layout if i == 0 else None, projection_size=projection_size)
             for i in range(num_layers))
 
     def forward(self, x):

@@ -246,7 +246,9 @@ def sru_fwd(U, xres, wc, bias, mask, T, B, d, k, keep_c=True):
     """-> (h, c); keep_c=False (inference) skips the cell-state store and returns c = None."""
     _need_cuda(U, "U")
     h = torch.empty((T, B, 2 * d), dtype=U.dtype, device=U.device)
-    c = torch.empty((T, B, 2 * d), dtype=U.dtype, device=U.device) if keep_c else None
+    # cell states kept for the backward: bf16 on the bf16 kernels (as the sru package does), f32 otherwise
+    cdt = torch.bfloat16 if U.dtype == torch.bfloat16 else torch.float32
+    c = torch.empty((T, B, 2 * d), dtype=cdt, device=U.device) if keep_c else None
     with torch.cuda.device(U.device):
         check(lib().sp_sru_fwd(ptr(U), ptr(xres), ptr(wc), ptr(bias), ptr(mask), T, B, d, k,
                                _lib.dtype_code(U), ptr(h), ptr(c), stream_ptr()), "sp_sru_fwd")
@@ -495,7 +497,7 @@ def _classifier_pack(weight, dtype, M):
     the problem is big enough for the persistent kernels (logits and their gradient are then [M, Vp] buffers of
     which the CTC kernels see the first V columns)."""
     V, n = weight.shape
-    if dtype != torch.bfloat16 or M < 4096 or n % 256 or V % _VPAD == 0:
+    if dtype not in (torch.bfloat16, torch.float16) or M < 4096 or n % 256 or V % _VPAD == 0:
         return weight.detach().to(dtype), V
     Vp = (V + _VPAD - 1) // _VPAD * _VPAD
     wb = torch.zeros((Vp, n), dtype=dtype, device=weight.device)
@@ -513,7 +515,7 @@ def _classifier_logits(x2d, weight):
 def _classifier_dx(gb, wb, scale=None):
     """gb [M, Vp] (pad columns zero) times wb [Vp, n]; with a padded weight as an NT product on wb^T."""
     w = wb if scale is None else (wb.float() * scale).to(wb.dtype)
-    if wb.shape[0] % _VPAD == 0 and gb.shape[0] >= 4096 and wb.dtype == torch.bfloat16:
+    if wb.shape[0] % _VPAD == 0 and gb.shape[0] >= 4096 and wb.dtype in (torch.bfloat16, torch.float16):
         return gemm(gb, w.t().contiguous())
     return gemm(gb, w.t())
 
@@ -612,7 +614,7 @@ def _nt_projection(M, n_in, N, d, dtype):
     bf16, output-heavy (N >= 2 n_in), enough rows for one 192-row tile per CU and column.  That layout
     is worth 15 % on this GEMM (profiles/r01_gemm.md): K-contiguous rows of both operands are what the
     LDS-DMA kernels stream, and the pitch padding keeps 256 CUs off a 2 KB row stride."""
-    return (dtype == torch.bfloat16 and N % 256 == 0 and n_in % 64 == 0 and d % 64 == 0 and N >= 2 * n_in
+    return (dtype in (torch.bfloat16, torch.float16) and N % 256 == 0 and n_in % 64 == 0 and d % 64 == 0 and N >= 2 * n_in
             and (M // 192) * (N // 256) >= 256 and M * max(n_in, N) < (1 << 30))
 
 
@@ -686,6 +688,33 @@ class _SRULayerFn(torch.autograd.Function):
             return (gx.view(T, B, n_in), dg.to(p[0]), db.to(p[1]), None, None, None, None, None, None, None, None)
         return (gx.view(T, B, n_in), dg.to(p[0]), db.to(p[1]), gw.to(p[2]), gwc.to(p[3]), gbias.to(p[4]),
                 None, None, None, None, None)
+
+
+class _MatmulFn(torch.autograd.Function):
+    """y = a @ w for activations a [M, K] and an f32 parameter(-derived) matrix w [K, N]: the product runs in a's
+    dtype on sp_gemm (f32 accumulation), the weight gradient a^T g comes back in f32."""
+
+    @staticmethod
+    def forward(ctx, a, w):
+        wb = w.detach().to(a.dtype).contiguous()
+        ctx.save_for_backward(a, wb)
+        ctx.wdtype = w.dtype
+        return gemm(a, wb.t())
+
+    @staticmethod
+    def backward(ctx, g):
+        a, wb = ctx.saved_tensors
+        g = g.contiguous()
+        ga = gemm(g, wb) if ctx.needs_input_grad[0] else None
+        gw = None
+        if ctx.needs_input_grad[1]:
+            gw = _splitk_dw(a, g).sum(0).to(ctx.wdtype)
+        return ga, gw
+
+
+def matmul(a, w):
+    """a [M, K] (activation dtype) @ w [K, N] (parameter, any float dtype) -> [M, N] in a's dtype, differentiable."""
+    return _MatmulFn.apply(a, w)
 
 
 def sru_layer(x, ln_w, ln_b, weight, wc, bias, mask, d, k, C=1, eps=1e-5):

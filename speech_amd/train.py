@@ -393,7 +393,7 @@ def main(hparams):
     rank, world = setup_distributed()
     torch.manual_seed(7 + rank)
     log = print if rank == 0 else (lambda *a, **k: None)
-    dtype = {"bf16": torch.bfloat16, "fp32": torch.float32}[hparams["dtype"]]
+    dtype = {"bf16": torch.bfloat16, "fp16": torch.float16, "fp32": torch.float32}[hparams["dtype"]]
     model = net.SRModel(hparams["n_rnn_layers"], hparams["rnn_dim"], hparams["n_vocab"], hparams["n_feats"],
                         hparams["dropout"], hparams["projection_size"], compute_dtype=dtype).cuda()
     if hparams.get("resume"):
@@ -441,7 +441,7 @@ def parse_args(argv=None):
     p.add_argument("--synthetic", action="store_true")
     p.add_argument("--synthetic_clips", type=int, default=512)
     p.add_argument("--steps", type=int, default=0)
-    p.add_argument("--dtype", choices=["bf16", "fp32"], default="bf16")
+    p.add_argument("--dtype", choices=["bf16", "fp16", "fp32"], default="bf16")
     p.add_argument("--checkpoint", type=str, default="")
     p.add_argument("--resume", type=str, default="", help="checkpoint to start from (either shape the reference writes)")
     p.add_argument("--eval_dtype", choices=["fp32", "same"], default="fp32")

@@ -312,6 +312,7 @@ def _sru_ref(U, x, wc, bias, mask, d):
 
 @pytest.mark.parametrize("k", [3, 4])
 @pytest.mark.parametrize("dtype,tol,T,d", [(torch.float32, 2e-5, 37, 64), (torch.bfloat16, 2e-2, 37, 64),
+                                           (torch.float16, 3e-3, 37, 64), (torch.float16, 3e-3, 131, 128),   # fp16: the reference's eval type
                                            (torch.bfloat16, 2e-2, 131, 128),   # loader-ring kernels
                                            (torch.bfloat16, 2e-2, 7, 256), (torch.bfloat16, 2e-2, 64, 128),
                                            (torch.bfloat16, 2e-2, 1, 64), (torch.bfloat16, 2e-2, 2, 64), (torch.bfloat16, 2e-2, 6, 64)])
@@ -548,7 +549,7 @@ def test_conv_stack_backward(cuda):
 
 
 # =============================================================================== layer norm
-@pytest.mark.parametrize("dtype,tol", [(torch.float32, 1e-5), (torch.bfloat16, 1.5e-2)])
+@pytest.mark.parametrize("dtype,tol", [(torch.float32, 1e-5), (torch.bfloat16, 1.5e-2), (torch.float16, 2e-3)])
 @pytest.mark.parametrize("shape", [(37, 1024), (5, 1280), (130, 64), (3, 2048)])
 def test_layernorm_fwd_bwd(cuda, dtype, tol, shape):
     from speech_amd import ops
@@ -886,3 +887,19 @@ def test_mel_per_utterance_normalisation(cuda, log):
         y[:, t0:t0 + tw] = 0
         assert float((out[b, 0, :, :tb].double() - y).abs().max()) <= 2e-4 * float(y.abs().max())
         assert float(out[b, 0, :, tb:].abs().max() if tb < out.shape[-1] else 0.0) == 0
+
+
+@pytest.mark.parametrize("M,N,K,out_dtype", [(24032, 3072, 1024, torch.float16), (24032, 1024, 3072, torch.float16),
+                                            (5000, 1024, 1024, torch.float32), (3000, 384, 192, torch.float16)])
+def test_gemm_nt_fp16(cuda, M, N, K, out_dtype):
+    """fp16 operands (the reference's evaluation type, model.half()) on the same role-split kernel
+    (v_mfma_f32_16x16x32_f16), f16 or f32 out."""
+    from speech_amd import ops
+    g = torch.Generator().manual_seed(M + N + K + 1)
+    a = torch.randn(M, K, generator=g).half().to(cuda)
+    b = (torch.randn(N, K, generator=g) * 0.1).half().to(cuda)
+    out = ops.gemm(a, b, out_dtype=out_dtype)
+    ref = a.float() @ b.float().t()
+    tol = 1e-3 if out_dtype == torch.float16 else 1e-5
+    assert out.dtype == out_dtype
+    assert float((out.float() - ref).abs().max()) <= tol * float(ref.abs().max()) + 1e-4

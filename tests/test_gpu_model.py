@@ -7,6 +7,7 @@ import torch
 from oracle import decode as odec
 from oracle import mel as omel
 from oracle import net as onet
+from oracle import sru as osru
 from oracle import text as otext
 
 pytestmark = pytest.mark.gpu
@@ -549,3 +550,82 @@ def test_bench_self_launch_path(cuda):
     d = json.loads(lines[0])
     assert d["n_gpus"] == 1 and d["steps"] == 2 and d["unit"] == "audio-sec/sec" and d["value"] > 0
     assert d["roofline"]["bound"] in ("hbm", "mfma") and 0 < d["roofline"]["frac"] < 1
+
+
+def test_model_forward_fp16(cuda):
+    """compute_dtype = float16 (the reference evaluates with model.half(), scripts/eval_dataset.py): LayerNorm, the
+    projections, the recurrence and the classifier run on their f16 instantiations; logits against the CPU
+    oracle, and decode parity on them."""
+    from speech_amd import decoder
+    m = _small_model(cuda, torch.float16).eval()
+    g = torch.Generator().manual_seed(2)
+    spec = torch.rand(3, 1, 80, 141, generator=g) * 3
+    sd = {k: v.detach().cpu().clone() for k, v in m.state_dict().items()}
+    with torch.no_grad():
+        out = m(spec.to(cuda))
+        ref = onet.forward(sd, spec, 2, 64, training=False)
+    assert out.dtype == torch.float32 and out.shape == ref.shape
+    assert float((out.cpu() - ref).abs().max()) <= 5e-2 * float(ref.abs().max())      # the conv stack keeps bf16 activations
+    assert decoder.greedy_decode_ids(out) == odec.greedy_decode_ids(out.cpu())
+
+
+def test_sru_layer_fp16_big_shape(cuda):
+    """One 4608-row SRU layer in fp16 (persistent NT kernel on the packed W^T, generic recurrence kernel) against
+    the same layer in fp32."""
+    from speech_amd import ops
+    torch.manual_seed(6)
+    T, B, d, k = 72, 64, 512, 3
+    n_in = 2 * d
+    x0 = torch.randn(T, B, n_in, device=cuda) * 0.7
+    ln_w, ln_b = torch.rand(n_in, device=cuda) + 0.5, torch.randn(n_in, device=cuda) * 0.1
+    weight = torch.randn(n_in, 2 * d * k, device=cuda) * (1.0 / n_in) ** 0.5
+    wc, bias = torch.randn(4 * d, device=cuda) * 0.3, torch.randn(4 * d, device=cuda) * 0.1
+    gh = torch.randn(T, B, 2 * d, device=cuda)
+    res = []
+    for dt in (torch.float32, torch.float16):
+        ps = [p.clone().requires_grad_(True) for p in (ln_w, ln_b, weight, wc, bias)]
+        x = x0.clone().to(dt).requires_grad_(True)
+        h = ops.sru_layer(x, *ps, None, d, k)
+        h.backward(gh.to(dt))
+        res.append((h.detach().float(), x.grad.float(), ps[2].grad.float()))
+    for a, b, tol in zip(res[1], res[0], (4e-3, 4e-3, 4e-3)):
+        assert float((a - b).abs().max()) <= tol * float(b.abs().max())
+
+
+@pytest.mark.parametrize("dtype,tol", [(torch.float32, 1e-4), (torch.bfloat16, 3e-2)])
+def test_sru_projection_size(cuda, dtype, tol):
+    """projection_size = p > 0 (net.py:65, train.py:319 --projection_size): U = (LN(x) weight_proj) weight.  The
+    factorised layer equals the plain layer with the product matrix weight_proj @ weight -- checked against the CPU
+    oracle's layer on that product, outputs and all gradients (chain rule through the factors)."""
+    from speech_amd import net
+    torch.manual_seed(8)
+    T, B, d, n_in, p = 19, 3, 64, 128, 32
+    cell = net.SRUCell(n_in, d, dropout=0.0, projection_size=p).to(cuda)
+    assert tuple(cell.weight_proj.shape) == (n_in, p) and tuple(cell.weight.shape) == (p, 2 * d * 3)
+    with torch.no_grad():
+        cell.weight.mul_(10.0)
+        cell.bias.uniform_(-0.2, 0.2)
+    x = torch.randn(T, B, n_in, device=cuda)
+    xd = x.clone().to(dtype).requires_grad_(True)
+    h = cell(xd)
+    gh = torch.randn(T, B, 2 * d, device=cuda)
+    h.backward(gh.to(dtype))
+    # oracle on W_eff = weight_proj @ weight, with the factors as leaves
+    wp = cell.weight_proj.detach().cpu().double().requires_grad_(True)
+    w = cell.weight.detach().cpu().double().requires_grad_(True)
+    xr = x.detach().cpu().double().requires_grad_(True)
+    ln = cell.layer_norm
+    href, _ = osru.sru_layer(xr, wp @ w, cell.weight_c.detach().cpu().double(), cell.bias.detach().cpu().double(),
+                             ln.weight.detach().cpu().double(), ln.bias.detach().cpu().double(), d)
+    href.backward(gh.cpu().double())
+
+    def close(a, b, what):
+        a, b = a.detach().cpu().double(), b.detach()
+        assert float((a - b).abs().max()) <= tol * max(1e-6, float(b.abs().max())), what
+    close(h, href, "h"); close(xd.grad, xr.grad, "gx")
+    close(cell.weight_proj.grad, wp.grad, "gweight_proj"); close(cell.weight.grad, w.grad, "gweight")
+    # and inside the whole model with the reference's constructor argument
+    m = net.SRModel(2, 64, 28, 80, 0.0, 32, compute_dtype=dtype).to(cuda)
+    assert "sru_layers.rnn_lst.0.weight_proj" in m.state_dict()
+    out = m(torch.rand(2, 1, 80, 101, device=cuda))
+    assert out.shape == (2, 51, 29) and torch.isfinite(out).all()

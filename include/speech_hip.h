@@ -125,6 +125,47 @@ int sp_greedy_decode(const void* scores, int dtype, int B, int T, int V, int bla
 int sp_edit_distance(const int32_t* a, int na, const int32_t* b, int nb);
 
 /* ---------------------------------------------------------------------------------------
+ * CTC prefix beam search with an n-gram language model.  Replaces the pyctcdecode path of
+ * scripts/eval_dataset.py:20-27 (build_ctcdecoder(list(text.CHARS), <kenlm scorer>, alpha=0.3, beta=1.0))
+ * and :43-51 (decode_batch(pool, logits.cpu().numpy())).  Parity unpinned: pyctcdecode and kenlm are not
+ * installed where this was built; the scoring rules are the published ones (see csrc/beam.hip) and the
+ * tests compare with an exhaustive enumeration of tiny lattices.
+ *
+ * sp_beam_candidates (GPU, asynchronous on `stream`): scores [B][T][V] contiguous logits (any of
+ * SP_F32/F16/BF16; log-probabilities are logits too).  Per frame: log-softmax, clip to [log 1e-15, 0], then
+ * every token with log p >= token_min_logp plus the argmax, ascending by id: cand_n[B*T] (the TRUE count,
+ * which may exceed kmax: the search then refuses the frame), cand_id / cand_lp [B*T][kmax].  A frame at or
+ * past frame_lengths[b] (device int32 [B] or NULL) gets count 0.  kmax >= min(V, floor(exp(-token_min_logp)) + 2)
+ * can never overflow.
+ *
+ * sp_ngram_load_arpa (host): reads an ARPA text file; alpha / beta weight log p(word | history) (natural
+ * log) and the per-word bonus, unk_score_offset (log10 units, pyctcdecode's -10) is added to a word that is
+ * not a unigram and, while a word is open, to a prefix that starts no unigram; score_boundary adds <s> / </s>.
+ * sp_ngram_score_sentence returns the plain log10 probability of a word sequence (for tests and tools).
+ *
+ * sp_ctc_beam_decode (host pointers throughout, blocking, n_threads worker threads over utterances):
+ * label_codepoints[V] gives one Unicode code point per token (the blank's is ignored); `space` is the word
+ * separator's id (-1: none; then lm must be NULL).  frame_lengths host int32 [B] or NULL.  Output per
+ * utterance the n_best hypotheses, best first: out_ids [B][n_best][max_out] (token ids, words separated by
+ * single spaces, -1 padded), out_len [B][n_best] (-1 = fewer hypotheses survived), out_scores
+ * [B][n_best][2] = (log-sum-exp of the CTC alignments, that + language-model score).
+ * --------------------------------------------------------------------------------------- */
+int sp_beam_candidates(const void* scores, int dtype, int B, int T, int V, float token_min_logp,
+                       const int32_t* frame_lengths, int kmax, int32_t* cand_n, int32_t* cand_id,
+                       float* cand_lp, void* stream);
+int sp_ngram_load_arpa(const char* path, float alpha, float beta, float unk_score_offset,
+                       int score_boundary, void** handle);
+void sp_ngram_free(void* handle);
+int sp_ngram_order(const void* handle);
+int sp_ngram_score_sentence(const void* handle, const char* const* words, int n, int bos, int eos,
+                            double* log10_total);
+int sp_ctc_beam_decode(const int32_t* cand_n, const int32_t* cand_id, const float* cand_lp, int B, int T,
+                       int kmax, const int32_t* frame_lengths, const int32_t* label_codepoints, int V,
+                       int blank, int space, const void* lm, int beam_width, float beam_prune_logp,
+                       int n_threads, int n_best, int max_out, int32_t* out_ids, int32_t* out_len,
+                       float* out_scores);
+
+/* ---------------------------------------------------------------------------------------
  * SRU recurrence.  Replaces the `sru` package's fused recurrence kernel invoked through
  * net.py:61-72 (sru.SRU(..., bidirectional=True, layer_norm=True, rescale=False,
  * highway_bias=0)).  One launch = one layer, both directions.

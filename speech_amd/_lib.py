@@ -31,6 +31,12 @@ SIGNATURES = {
                                     _vp, _i, _vp]),
     "sp_greedy_decode": (_i, [_vp, _i, _i, _i, _i, _i, _vp, _vp, _vp, _vp]),
     "sp_edit_distance": (_i, [_vp, _i, _vp, _i]),
+    "sp_beam_candidates": (_i, [_vp, _i, _i, _i, _i, _f, _vp, _i, _vp, _vp, _vp, _vp]),
+    "sp_ngram_load_arpa": (_i, [_c.c_char_p, _f, _f, _f, _i, _c.POINTER(_vp)]),
+    "sp_ngram_free": (None, [_vp]),
+    "sp_ngram_order": (_i, [_vp]),
+    "sp_ngram_score_sentence": (_i, [_vp, _c.POINTER(_c.c_char_p), _i, _i, _i, _c.POINTER(_c.c_double)]),
+    "sp_ctc_beam_decode": (_i, [_vp, _vp, _vp, _i, _i, _i, _vp, _vp, _i, _i, _i, _vp, _i, _f, _i, _i, _i, _vp, _vp, _vp]),
     "sp_sru_fwd": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp, _vp, _vp]),
     "sp_sru_bwd": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp, _vp, _vp, _vp,
                         _vp]),

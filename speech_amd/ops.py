@@ -4,6 +4,7 @@ normalisations, every matrix product, recurrence, CTC, decode -- runs in the han
 kernels.  What is left to torch are dtype casts and scalings of parameter-sized tensors and the
 dropout masks' random draws."""
 import ctypes
+import math
 
 import numpy as np
 import torch
@@ -237,6 +238,62 @@ def edit_distance(a, b):
     if r < 0:
         raise _lib.SpeechHipError("sp_edit_distance failed")
     return r
+
+
+# ------------------------------------------------------------------------------------------
+# Beam search (scripts/eval_dataset.py:20-27, :43-51)
+# ------------------------------------------------------------------------------------------
+def beam_kmax(V, token_min_logp):
+    """Candidate-list width that cannot overflow: at most floor(exp(-min)) tokens reach the threshold."""
+    if token_min_logp <= -34.0:
+        return int(V)
+    return int(min(V, math.floor(math.exp(-token_min_logp)) + 2))
+
+
+def beam_candidates(scores, token_min_logp=-5.0, frame_lengths=None, kmax=None):
+    """scores [B,T,V] logits on the device -> (cand_n int32 [B,T], cand_id int32 [B,T,kmax],
+    cand_lp f32 [B,T,kmax]) on the device: per frame the tokens a beam search expands."""
+    _need_cuda(scores, "scores")
+    if scores.dim() != 3:
+        raise ValueError("scores must be [B, T, V]")
+    scores = scores.contiguous()
+    B, T, V = scores.shape
+    kmax = beam_kmax(V, token_min_logp) if kmax is None else int(kmax)
+    cand_n = torch.empty((B, T), dtype=torch.int32, device=scores.device)
+    cand_id = torch.empty((B, T, kmax), dtype=torch.int32, device=scores.device)
+    cand_lp = torch.empty((B, T, kmax), dtype=torch.float32, device=scores.device)
+    fl = None
+    if frame_lengths is not None:
+        fl = torch.as_tensor(frame_lengths).to(device=scores.device, dtype=torch.int32).contiguous()
+    with torch.cuda.device(scores.device):
+        check(lib().sp_beam_candidates(ptr(scores), _lib.dtype_code(scores), B, T, V, float(token_min_logp), ptr(fl),
+                                       kmax, ptr(cand_n), ptr(cand_id), ptr(cand_lp), stream_ptr()), "sp_beam_candidates")
+    return cand_n, cand_id, cand_lp
+
+
+def ctc_beam_decode(cand_n, cand_id, cand_lp, codepoints, blank, space, lm_handle=None, beam_width=100,
+                    beam_prune_logp=-10.0, frame_lengths=None, n_threads=16, n_best=1, max_out=None):
+    """Host prefix beam search over candidate lists (numpy arrays, shapes as beam_candidates returns).
+    -> (ids int32 [B,n_best,max_out], lengths int32 [B,n_best], scores f32 [B,n_best,2])."""
+    cand_n = np.ascontiguousarray(cand_n, dtype=np.int32)
+    cand_id = np.ascontiguousarray(cand_id, dtype=np.int32)
+    cand_lp = np.ascontiguousarray(cand_lp, dtype=np.float32)
+    B, T = cand_n.shape
+    kmax = cand_id.shape[2]
+    if cand_id.shape != (B, T, kmax) or cand_lp.shape != (B, T, kmax):
+        raise ValueError("candidate arrays disagree in shape")
+    cps = np.ascontiguousarray(codepoints, dtype=np.int32)
+    max_out = T if max_out is None else int(max_out)
+    fl = None if frame_lengths is None else np.ascontiguousarray(frame_lengths, dtype=np.int32)
+    out_ids = np.empty((B, n_best, max(max_out, 1)), dtype=np.int32)
+    out_len = np.empty((B, n_best), dtype=np.int32)
+    out_sc = np.empty((B, n_best, 2), dtype=np.float32)
+    vp = lambda a: None if a is None else ctypes.c_void_p(a.ctypes.data)
+    check(lib().sp_ctc_beam_decode(vp(cand_n), vp(cand_id), vp(cand_lp), B, T, kmax, vp(fl), vp(cps), cps.size,
+                                   int(blank), int(space), lm_handle, int(beam_width), float(beam_prune_logp),
+                                   int(n_threads), int(n_best), max(max_out, 1), vp(out_ids), vp(out_len), vp(out_sc)),
+          "sp_ctc_beam_decode")
+    return out_ids, out_len, out_sc
 
 
 # ------------------------------------------------------------------------------------------

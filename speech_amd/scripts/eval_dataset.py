@@ -1,19 +1,24 @@
 """Batched inference and CER/WER -- same surface as the reference's scripts/eval_dataset.py:19-129
-(``test(dataset_type, batch_size, model, test_loader, beam_decode)``); greedy decoding only (the
-pyctcdecode beam + KenLM path, eval_dataset.py:20-27, is SURVEY section 8f item 3, not built).
+(``test(dataset_type, batch_size, model, test_loader, beam_decode)``).  With ``beam_decode`` the logits go
+through ``decoder.build_ctcdecoder(list(text.CHARS), <ARPA file>, alpha=0.3, beta=1.0).decode_batch`` as in
+eval_dataset.py:20-27 and :43-51 (candidate lists on the GPU, prefix search on native host threads).
 
     python -m speech_amd.scripts.eval_dataset False synthetic [model.pth]
+    python -m speech_amd.scripts.eval_dataset True synthetic model.pth lm.arpa
 """
 import sys
 
 import torch
 
-from .. import data, decoder, net
+from .. import data, decoder, net, text
 
 
-def test(dataset_type, batch_size, model, test_loader, beam_decode=False, log=print):
+def test(dataset_type, batch_size, model, test_loader, beam_decode=False, log=print, lm_path=None,
+         alpha=0.3, beta=1.0):
+    ctc_decoder = None
     if beam_decode:
-        raise NotImplementedError("beam search with a KenLM scorer is not part of this build")
+        # eval_dataset.py:20-27; lm_path None searches without a language model
+        ctc_decoder = decoder.build_ctcdecoder(list(text.CHARS), lm_path, alpha=alpha, beta=beta)
     log("\nevaluating...")
     model.eval()
     test_cer, test_wer = [], []
@@ -22,7 +27,11 @@ def test(dataset_type, batch_size, model, test_loader, beam_decode=False, log=pr
             spectrograms, labels, label_lengths = batch
             logits = model(spectrograms.cuda())                       # [B, T', V]
             # eval_dataset.py:40 takes log_softmax first; the greedy path is invariant to it
-            preds, targets = decoder.greedy_decoder(logits, labels, label_lengths)
+            if ctc_decoder is not None:
+                preds = ctc_decoder.decode_batch(None, logits)        # eval_dataset.py:43-51, raw logits
+                targets = [text.int_to_text(labels[j][: label_lengths[j]].tolist()) for j in range(len(preds))]
+            else:
+                preds, targets = decoder.greedy_decoder(logits, labels, label_lengths)
             for tgt, pred in zip(targets, preds):
                 test_cer.append(decoder.cer(tgt, pred))
                 test_wer.append(decoder.wer(tgt, pred))
@@ -46,4 +55,4 @@ if __name__ == "__main__":
         raise SystemExit("only the synthetic corpus is available here (the reference's manifests point at /hd1)")
     ds = data.SyntheticSorted(256, hparams["batch_size"], max_s=8.0, seed=3)
     loader = [data.collate_fn(ds[i], "valid") for i in range(len(ds))]
-    test(dataset_type, hparams["batch_size"], model, loader, beam_decode)
+    test(dataset_type, hparams["batch_size"], model, loader, beam_decode, lm_path=sys.argv[4] if len(sys.argv) > 4 else None)

@@ -903,3 +903,72 @@ def test_gemm_nt_fp16(cuda, M, N, K, out_dtype):
     tol = 1e-3 if out_dtype == torch.float16 else 1e-5
     assert out.dtype == out_dtype
     assert float((out.float() - ref).abs().max()) <= tol * float(ref.abs().max()) + 1e-4
+
+
+# ------------------------------------------------------------------------------------------
+# beam search (scripts/eval_dataset.py:20-27, :43-51): the GPU candidate stage and the whole decoder
+# ------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("dtype", [torch.float32, torch.float16, torch.bfloat16])
+@pytest.mark.parametrize("V", [29, 1000])
+def test_beam_candidates_match_the_oracle(cuda, dtype, V):
+    from oracle import beam as obeam
+    from speech_amd import ops
+    g = torch.Generator().manual_seed(V)
+    B, T = 3, 57
+    x = (torch.randn(B, T, V, generator=g) * 4).to(dtype)
+    fl = torch.tensor([T, 31, 0], dtype=torch.int32)
+    cn, ci, cl = ops.beam_candidates(x.to(cuda), -5.0, fl)
+    cn, ci, cl = cn.cpu().numpy(), ci.cpu().numpy(), cl.cpu().numpy()
+    assert ci.shape[2] == min(V, 150)
+    for b in range(B):
+        want = obeam.candidates(x[b].float().numpy(), -5.0)
+        for t in range(T):
+            if t >= fl[b]:
+                assert cn[b, t] == 0
+                continue
+            w = want[t]
+            got_ids = ci[b, t, : cn[b, t]].tolist()
+            lp = dict(zip(got_ids, cl[b, t, : cn[b, t]].tolist()))
+            # a token within float rounding of the threshold may fall on either side
+            sure = [i for i, p in w if abs(p + 5.0) > 1e-3]
+            assert got_ids == sorted(got_ids)
+            assert set(sure) <= set(got_ids) and all(abs(lp[i] - p) < 2e-4 for i, p in w if i in lp)
+            assert all(i in dict(w) or abs(lp[i] + 5.0) < 1e-3 for i in got_ids)
+
+
+def test_beam_decoder_end_to_end(cuda, tmp_path):
+    """decoder.build_ctcdecoder(...).decode_batch on device logits = the oracle's search on the same logits;
+    a peaked lattice decodes to its greedy text; the language model changes the winner where it should."""
+    from oracle import beam as obeam
+    from speech_amd import decoder, text
+    labels = list(text.CHARS)
+    arpa = tmp_path / "lm.arpa"
+    arpa.write_text("\\data\\\nngram 1=6\nngram 2=2\n\n\\1-grams:\n-1.5\t<unk>\n-99\t<s>\t-0.3\n-1.0\t</s>\n"
+                    "-0.5\tthe\t-0.2\n-0.8\tcat\t-0.2\n-2.5\ttha\n\n\\2-grams:\n-0.2\tthe cat\n-0.3\t<s> the\n\n\\end\\\n")
+    dec0 = decoder.build_ctcdecoder(labels, None)
+    dec1 = decoder.build_ctcdecoder(labels, str(arpa), alpha=0.3, beta=1.0)
+    g = torch.Generator().manual_seed(9)
+    x = torch.randn(5, 40, len(labels), generator=g) * 3
+    got0 = dec0.decode_batch(None, x.to(cuda), beam_width=16)
+    got1 = dec1.decode_batch(None, x.half().to(cuda), beam_width=16)
+    lm = obeam.ArpaLM(str(arpa), 0.3, 1.0)
+    for b in range(5):
+        assert got0[b] == obeam.prefix_beam(x[b].numpy(), dec0.labels, dec0.blank, None, 16)[0][0]
+        assert got1[b] == obeam.prefix_beam(x[b].half().float().numpy(), dec0.labels, dec0.blank, lm, 16)[0][0]
+    # a peaked lattice spelling "the cat": beam = greedy; numpy input and a list of ragged arrays work too
+    ids = [labels.index(c) for c in "the cat"]
+    frames = []
+    for i in ids:
+        frames += [i, 0]
+    peaked = torch.full((len(frames), len(labels)), -8.0)
+    peaked[torch.arange(len(frames)), torch.tensor(frames)] = 8.0
+    assert dec0.decode(peaked.numpy()) == "the cat" and dec1.decode(peaked.to(cuda)) == "the cat"
+    assert dec0.decode_batch(None, [peaked.numpy(), peaked[:6].numpy()]) == ["the cat", "the"]
+    # ambiguous last vowel of the first word: acoustics prefer "tha", the language model "the"
+    amb = peaked.clone()
+    pos = frames.index(labels.index("e"))
+    amb[pos, labels.index("e")] = 2.0
+    amb[pos, labels.index("a")] = 2.6
+    assert dec0.decode(amb.to(cuda)) == "tha cat" and dec1.decode(amb.to(cuda)) == "the cat"
+    beams = dec1.decode_beams(amb.to(cuda), n_best=3)
+    assert beams[0][0] == "the cat" and beams[0][2] >= beams[1][2]

@@ -228,6 +228,13 @@ def test_scripts_predict_and_eval(cuda, tmp_path):
     loader = [data.collate_fn(ds[i], "valid") for i in range(len(ds))]
     cer, wer = eval_dataset.test("synthetic", 4, m2, loader, False, log=lambda *a: None)
     assert cer >= 0 and wer >= 0
+    # beam_decode=True (eval_dataset.py:20-27, :43-51), without and with a language model
+    cer_b, wer_b = eval_dataset.test("synthetic", 4, m2, loader, True, log=lambda *a: None)
+    assert cer_b >= 0 and wer_b >= 0
+    arpa = tmp_path / "lm.arpa"
+    arpa.write_text("\\data\\\nngram 1=5\n\n\\1-grams:\n-1.0\t<unk>\n-99\t<s>\n-1.0\t</s>\n-0.6\tthe\n-0.9\tcat\n\n\\end\\\n")
+    cer_l, wer_l = eval_dataset.test("synthetic", 4, m2, loader, True, log=lambda *a: None, lm_path=str(arpa))
+    assert cer_l >= 0 and wer_l >= 0
 
 
 def test_grad_sink_matches_autograd_accumulation(cuda):

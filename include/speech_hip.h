@@ -278,10 +278,14 @@ int sp_block_bwd_in(const void* gz, const void* z, int64_t zsb, int64_t zsf, int
  * buffer).  sp_sru_pack_wt: the same weight transposed, WkT[k][dir][d][n_in] with row pitch ldo elements
  * (>= n_in, even): the K-contiguous B operand of sp_gemm for the forward projection; with out_w
  * != NULL the same pass also writes sp_sru_pack_w's Wk there (what the data gradient's GEMM reads).
- * n_in % 64 == 0 (bf16; 32 for f32), d % 64 == 0. */
+ * n_in % 64 == 0 (bf16; 32 for f32), d % 64 == 0.  sp_sru_pack_wt_batched: the same for L <= 16 layers of
+ * one shape in ONE launch; weights / out_t / out_w are HOST arrays of L device pointers (out_w NULL: none;
+ * weight pointers 16-byte aligned). */
 int sp_sru_pack_w(const float* weight, int n_in, int d, int k, int C, int dtype, void* out, void* stream);
 int sp_sru_pack_wt(const float* weight, int n_in, int d, int k, int C, int dtype, void* out_t, int64_t ldo,
                    void* out_w, void* stream);
+int sp_sru_pack_wt_batched(const float* const* weights, int L, int n_in, int d, int k, int C, int dtype,
+                           void* const* out_t, int64_t ldo, void* const* out_w, void* stream);
 int sp_sru_unpack_dw(const void* partials, int S, int n_in, int d, int k, int C, int dtype,
                      int accumulate, float* dweight, void* stream);
 

@@ -55,6 +55,7 @@ SIGNATURES = {
     "sp_block_bwd_in": (_i, [_vp, _vp, _i64, _i64, _i64, _vp, _i, _i, _i, _vp, _vp, _vp]),
     "sp_sru_pack_w": (_i, [_vp, _i, _i, _i, _i, _i, _vp, _vp]),
     "sp_sru_pack_wt": (_i, [_vp, _i, _i, _i, _i, _i, _vp, _i64, _vp, _vp]),
+    "sp_sru_pack_wt_batched": (_i, [_vp, _i, _i, _i, _i, _i, _i, _vp, _i64, _vp, _vp]),
     "sp_sru_unpack_dw": (_i, [_vp, _i, _i, _i, _i, _i, _i, _i, _vp, _vp]),
     "sp_gemm": (_i, [_vp, _vp, _vp, _i, _i, _i, _i64, _i64, _i64, _i64, _i64, _i, _i, _i, _i, _i64, _vp]),
     "sp_gemm_tn_splits": (_i, [_i, _i, _i, _i]),

@@ -112,9 +112,9 @@ class SRUCell(nn.Module):
             v = v.view(C, Fq).t().reshape(-1)
         return v.to(dtype)
 
-    def forward(self, x, mask=None):
+    def forward(self, x, mask=None, pre=None):
         """mask: optional pre-drawn variational dropout mask [B, 2d] (already / keep); SRU.forward draws
-        the masks of all layers in one call."""
+        the masks of all layers in one call.  pre: this layer's packed weights from ops.sru_prepack."""
         T, B, n_in = x.shape
         d = self.hidden_size
         ln = self.layer_norm
@@ -134,7 +134,7 @@ class SRUCell(nn.Module):
             U = ops.matmul(ops.matmul(xn.reshape(T * B, n_in), wp), wk).view(T, B, k, 2, d)
             return ops.sru_recurrence(U, x if k == 3 else None, self.weight_c, self.bias, mask, d)
         return ops.sru_layer(x, ln.weight, ln.bias, self.weight, self.weight_c, self.bias, mask, d,
-                             self.num_matrices, C, ln.eps)
+                             self.num_matrices, C, ln.eps, pre)
 
 
 class SRU(nn.Module):
@@ -165,9 +165,15 @@ class SRU(nn.Module):
                 if keep is None or keep.device != x.device or keep.shape[0] != len(drops):
                     keep = self._keep = torch.tensor([1.0 - p for p in drops], device=x.device).view(-1, 1, 1)
                 masks = torch.bernoulli(keep.expand(len(drops), B, d2)) / keep
+        # the packed projection weights of all same-shaped layers in one launch (nine of the ten here)
+        cells = [(c.weight, c.hidden_size, c.num_matrices, c.in_layout[0] if c.in_layout is not None else 1)
+                 for c in self.rnn_lst]
+        packs = {}
+        if x.is_cuda and all(c.projection_size == 0 for c in self.rnn_lst):
+            packs = ops.sru_prepack(cells, x.shape[0], x.shape[1], x.dtype, torch.is_grad_enabled())
         for i, cell in enumerate(self.rnn_lst):
             m = masks[i] if masks is not None and drops[i] > 0 else None
-            x = cell(x, m)
+            x = cell(x, m, packs.get(i))
         return x, None
 
 

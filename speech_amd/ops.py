@@ -524,6 +524,43 @@ def sru_pack_wt(weight, d, k, C, dtype, pad=0, both=False):
     return (out, out_w) if both else out
 
 
+def sru_pack_wt_many(weights, d, k, C, dtype, pad=0, both=False):
+    """sru_pack_wt for several layers of one shape in ONE launch -> list of (WkT, Wk or None)."""
+    L = len(weights)
+    n_in, dev = weights[0].shape[0], weights[0].device
+    res = []
+    for lo in range(0, L, 16):
+        ws = [w.detach().float().contiguous() for w in weights[lo:lo + 16]]
+        n = len(ws)
+        out = torch.empty((n, k * 2 * d, n_in + pad), dtype=dtype, device=dev)
+        out_w = torch.empty((n, n_in, k * 2 * d), dtype=dtype, device=dev) if both else None
+        arr = ctypes.c_void_p * n
+        pw = arr(*[w.data_ptr() for w in ws])
+        pt = arr(*[out[i].data_ptr() for i in range(n)])
+        po = arr(*[out_w[i].data_ptr() for i in range(n)]) if both else None
+        with torch.cuda.device(dev):
+            check(lib().sp_sru_pack_wt_batched(pw, n, n_in, d, k, C, _lib.dtype_code(out), pt, out.stride(1), po,
+                                               stream_ptr()), "sp_sru_pack_wt_batched")
+        res += [(out[i][:, :n_in], out_w[i] if both else None) for i in range(n)]
+    return res
+
+
+def sru_prepack(cells, T, B, dtype, train):
+    """The packed projection weights of every SRU layer that runs the NT projection, one launch per group of
+    same-shaped layers instead of one per layer.  cells: [(weight, d, k, C)] -> {index: (WkT, Wk or None)}."""
+    groups = {}
+    for i, (w, d, k, C) in enumerate(cells):
+        n_in = w.shape[0]
+        if _nt_projection(T * B, n_in, 2 * d * k, d, dtype):
+            groups.setdefault((n_in, d, k, C), []).append(i)
+    out = {}
+    for (n_in, d, k, C), idx in groups.items():
+        pad = 64 if (n_in * torch.empty((), dtype=dtype).element_size()) % 1024 == 0 else 0
+        packs = sru_pack_wt_many([cells[i][0] for i in idx], d, k, C, dtype, pad, both=train)
+        out.update(zip(idx, packs))
+    return out
+
+
 def sru_unpack_dw(partials, n_in, d, k, C, out=None):
     """split-K partials [S, n_in, k*2*d] -> f32 dweight [n_in, 2*d*k] in the state_dict layout; with
     `out` (the parameter's gradient buffer) the sum is ADDED to it."""
@@ -683,7 +720,7 @@ class _SRULayerFn(torch.autograd.Function):
     inverse for the gradients are HIP kernels (sp_sru_pack_w / sp_sru_unpack_dw)."""
 
     @staticmethod
-    def forward(ctx, x, ln_w, ln_b, weight, wc, bias, mask, d, k, C, eps):
+    def forward(ctx, x, ln_w, ln_b, weight, wc, bias, mask, d, k, C, eps, pre=None):
         T, B, n_in = x.shape
         x2 = x.contiguous().view(T * B, n_in)
         g32, b32 = ln_w.detach().float(), ln_b.detach().float()
@@ -696,7 +733,11 @@ class _SRULayerFn(torch.autograd.Function):
         xn, mean, rstd = layernorm_fwd(x2, g32, b32, eps, pad)
         w32 = weight.detach().float().contiguous()
         train = any(ctx.needs_input_grad)      # False under no_grad: nothing is kept for a backward
-        if own and train:      # W^T [N][n_in] for the forward (NT), W [n_in][N] for the data gradient
+        if own and pre is not None and (pre[1] is not None or not train):   # packed by sru_prepack with its siblings
+            wkt, wk = pre
+            U = gemm(xn, wkt)
+            del wkt
+        elif own and train:    # W^T [N][n_in] for the forward (NT), W [n_in][N] for the data gradient
             wkt, wk = sru_pack_wt(w32, d, k, C, x.dtype, pad, both=True)
             U = gemm(xn, wkt)
             del wkt
@@ -741,10 +782,10 @@ class _SRULayerFn(torch.autograd.Function):
             sink.ready(weight, wc, bias)
             if ln_direct:
                 sink.ready(ln_w, ln_b)
-                return (gx.view(T, B, n_in), None, None, None, None, None, None, None, None, None, None)
-            return (gx.view(T, B, n_in), dg.to(p[0]), db.to(p[1]), None, None, None, None, None, None, None, None)
+                return (gx.view(T, B, n_in), None, None, None, None, None, None, None, None, None, None, None)
+            return (gx.view(T, B, n_in), dg.to(p[0]), db.to(p[1]), None, None, None, None, None, None, None, None, None)
         return (gx.view(T, B, n_in), dg.to(p[0]), db.to(p[1]), gw.to(p[2]), gwc.to(p[3]), gbias.to(p[4]),
-                None, None, None, None, None)
+                None, None, None, None, None, None)
 
 
 class _MatmulFn(torch.autograd.Function):
@@ -774,5 +815,6 @@ def matmul(a, w):
     return _MatmulFn.apply(a, w)
 
 
-def sru_layer(x, ln_w, ln_b, weight, wc, bias, mask, d, k, C=1, eps=1e-5):
-    return _SRULayerFn.apply(x, ln_w, ln_b, weight, wc, bias, mask, d, k, C, eps)
+def sru_layer(x, ln_w, ln_b, weight, wc, bias, mask, d, k, C=1, eps=1e-5, pre=None):
+    """pre: this layer's entry of sru_prepack (its weights already packed), or None."""
+    return _SRULayerFn.apply(x, ln_w, ln_b, weight, wc, bias, mask, d, k, C, eps, pre)

@@ -225,10 +225,12 @@ int sp_adam_step_f32(float* p, const float* g, float* m, float* v, int64_t n, fl
  *   the pre-BN tensor); 2: out += epi_src (residual gradient).  Supported pairs: (0,0) (1,0) (2,1) (2,2).
  *   bn_sums (may be NULL): the BatchNorm reduction over the OUTPUT fused into the epilogue --
  *   epi_mode 0: what sp_bn_stats(out) gives; epi_mode 1: what sp_bn_bwd_reduce(out, epi_src) gives.
- *   Every `sums` / `bn_sums` buffer holds SP_BN_SUMS_WORDS floats: eight rows of 64 whose sum (taken
- *   in a fixed order by the sp_bn_finalize_* consumers) is the result, followed by one 64-float
- *   partial per workgroup of the producing launch.  No float atomics: statistics, and with them
- *   every bf16 activation, are bit-reproducible.
+ *   Every `sums` / `bn_sums` buffer holds SP_BN_SUMS_WORDS floats: eight rows of 64, then one 64-float
+ *   partial per workgroup of the producing launch (at most 1024), then one word with the number of
+ *   partials (an int).  The producers write the partials and the count; sp_bn_finalize_* adds the
+ *   partials into the eight rows in a fixed order (and leaves the rows in the buffer: their sum is
+ *   the result) before it uses them.  No float atomics: statistics, and with them every bf16
+ *   activation, are bit-reproducible.
  * sp_conv3x5_wgrad: gw[32][32][3][5] += sum_pos dy[pos][co] * a[pos + tap][ci], with
  *   a = a_src (a_mode 0) or relu(BN(a_src)) (a_mode 1), dy = g_coef affine of (g, y) as in_mode 2.
  *   gwp_ws: 8*15*32*32 f32 workspace, one partial copy per XCD.  Contract: the caller zeroes it ONCE (when it
@@ -236,7 +238,7 @@ int sp_adam_step_f32(float* p, const float* g, float* m, float* v, int64_t n, fl
  *   back-to-back calls need no fill.  After a failed call, or if two streams share one workspace, zero it again.
  * sp_conv_stem_fwd/bwd: Conv2d(1,32,3,stride 2,pad 1) on the f32 spectrogram [B][Fin][Tin] ->
  *   [B][F][T][32], F = (Fin-1)/2+1, T = (Tin-1)/2+1; bwd accumulates gw[32*9], gbias[32].
- * sp_bn_stats: (sum y | sum y^2) per channel, as eight rows sums[8][64] to be added.
+ * sp_bn_stats: (sum y | sum y^2) per channel, as per-workgroup partials in sums (see above).
  * sp_bn_bwd_reduce: sums = (sum g, sum g*y).
  * sp_bn_finalize_fwd: coef = (scale, shift), save = (mean, invstd); training != 0 uses the batch
  *   sums and updates running stats (momentum, unbiased variance), else uses running stats.
@@ -245,7 +247,7 @@ int sp_adam_step_f32(float* p, const float* g, float* m, float* v, int64_t n, fl
  *   which lets the last block write the [T][B][F*32] layout the SRU stack reads.
  * sp_block_bwd_in: gpre = gz * [z > 0] (gz, z in that layout); sums = (sum gpre, sum gpre*y2).
  * --------------------------------------------------------------------------------------- */
-#define SP_BN_SUMS_WORDS (8 * 64 + 1024 * 64)
+#define SP_BN_SUMS_WORDS (8 * 64 + 1024 * 64 + 64)
 int sp_conv_pack_w(const float* w, int bwd_data, void* wpack, void* stream);
 int sp_conv3x5(const void* in, const void* in2, const float* coef, int in_mode, const void* wpack,
                const float* bias, const void* epi_src, const float* epi_coef, int epi_mode, int B,
@@ -259,10 +261,10 @@ int sp_conv_stem_bwd(const float* spec, const void* gout, int B, int Fin, int Ti
                      float* gbias, void* stream);
 int sp_bn_stats(const void* y, int64_t npos, float* sums, void* stream);
 int sp_bn_bwd_reduce(const void* g, const void* y, int64_t npos, float* sums, void* stream);
-int sp_bn_finalize_fwd(const float* sums, int64_t npos, const float* gamma, const float* beta,
+int sp_bn_finalize_fwd(float* sums, int64_t npos, const float* gamma, const float* beta,
                        float* rmean, float* rvar, float momentum, float eps, int training,
                        float* coef, float* save, void* stream);
-int sp_bn_finalize_bwd(const float* sums, const float* save, const float* gamma, int64_t npos,
+int sp_bn_finalize_bwd(float* sums, const float* save, const float* gamma, int64_t npos,
                        float* coef3, float* ggamma, float* gbeta, void* stream);
 int sp_block_out(const void* y2, const float* coef, const void* x, int B, int F, int T, void* z,
                  int64_t zsb, int64_t zsf, int64_t zst, void* stream);

@@ -11,7 +11,7 @@ LIB_PATH = os.path.join(_HERE, "libspeech_hip.so")
 
 SP_F32, SP_F16, SP_BF16 = 0, 1, 2
 SUMSQ_WORDS = 1025   # SP_SUMSQ_WORDS of include/speech_hip.h
-BN_SUMS_WORDS = 8 * 64 + 1024 * 64   # SP_BN_SUMS_WORDS: [8][64] rows to add, then per-workgroup partials
+BN_SUMS_WORDS = 8 * 64 + 1024 * 64 + 64   # SP_BN_SUMS_WORDS: [8][64] rows, per-workgroup partials, their count
 
 _c = ctypes
 _vp, _i, _i64, _f, _sz = _c.c_void_p, _c.c_int, _c.c_int64, _c.c_float, _c.c_size_t

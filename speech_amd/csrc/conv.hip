@@ -27,6 +27,7 @@ typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
 constexpr int kC = 32;
+constexpr int kBnMaxParts = 1024, kBnCountWord = 8 * 64 + kBnMaxParts * 64;   // see SP_BN_SUMS_WORDS
 
 __device__ __forceinline__ void unpack8(const uint4& v, float (&f)[8]) {
     const uint32_t w[4] = {v.x, v.y, v.z, v.w};
@@ -311,8 +312,9 @@ __global__ __launch_bounds__(256, 2) void conv3x5_kernel(
             const int c4 = tid >> 4, k = tid & 15;
             const float sm = red[(0 * 4 + c4) * 16 + k] + red[(1 * 4 + c4) * 16 + k] + red[(2 * 4 + c4) * 16 + k] +
                              red[(3 * 4 + c4) * 16 + k];
-            bn_sums[(8 + blockIdx.x) * 64 + (k >> 3) * 32 + c4 * 8 + (k & 7)] = sm;   // partial; see bn_sum_parts_kernel
+            bn_sums[(8 + blockIdx.x) * 64 + (k >> 3) * 32 + c4 * 8 + (k & 7)] = sm;   // partial; see bn_rows
         }
+        if (blockIdx.x == 0 && tid == 0) bn_sums[kBnCountWord] = __int_as_float((int)gridDim.x);
     }
 }
 
@@ -754,52 +756,73 @@ __global__ __launch_bounds__(256) void bn_reduce_kernel(const __hip_bfloat16* __
         const float s = red[0][c4][k] + red[1][c4][k] + red[2][c4][k] + red[3][c4][k];
         sums[(8 + blockIdx.x) * 64 + (k >> 3) * 32 + c4 * 8 + (k & 7)] = s;
     }
+    if (blockIdx.x == 0 && threadIdx.x == 0) sums[kBnCountWord] = __int_as_float((int)gridDim.x);
 }
 
-// Second level of the BatchNorm reductions.  The producing launch leaves one 64-float partial per
-// workgroup at sums[kBnL2 * 64 + 64 b ..]; workgroup g of this kernel adds the partials b = g, g + 8, ...
-// in a FIXED order into row g of sums[0 .. kBnL2 * 64), and the consumers (bn_finalize_*) add those
-// eight rows in a fixed order.  No float atomics anywhere: the statistics, and through them every bf16
-// activation of the stack, are bit-reproducible from run to run and identical on data-parallel
-// replicas.  (Eight workgroups, not one: a single CU fetches the up to 256 KB of partials at ~60 GB/s.)
+// Second level of the BatchNorm reductions, fused into the finalising kernels.  The producing launch leaves one
+// 64-float partial per workgroup at sums[kBnL2 * 64 + 64 b ..] and the number of partials in sums[kBnCountWord].
+// The finaliser -- one workgroup of 1024 threads -- adds, for each of eight rows g, the partials b = g, g + 8, ...
+// in a FIXED order (four rows at a time, 256 threads per row), keeps the eight row sums in LDS, writes them to
+// sums[0 .. 512) for inspection, and adds the rows in a fixed order.  No float atomics anywhere: the statistics,
+// and through them every bf16 activation of the stack, are bit-reproducible from run to run and identical on
+// data-parallel replicas.  (The second level used to be a launch of its own, eight workgroups: 7 us, twelve
+// times a step, for at most 256 KB.)
 constexpr int kBnL2 = 8;
-__global__ __launch_bounds__(256) void bn_sum_parts_kernel(float* __restrict__ sums, int nparts) {
-    __shared__ float grp[4][64];
-    const int idx = threadIdx.x & 63, q = threadIdx.x >> 6;
+__device__ __forceinline__ void bn_rows(float* __restrict__ sums, float (*rows)[64], float (*grp)[4][64]) {
+    const int nparts = min(max(__float_as_int(sums[kBnCountWord]), 0), kBnMaxParts);   // 8 * (3 + 96 + 28) + 7 = 1023 is the last index covered
+    const int idx = threadIdx.x & 63, q = (threadIdx.x >> 6) & 3, vg = threadIdx.x >> 8;
     const float* part = sums + kBnL2 * 64;
-    float a[8];
+    // every load of this thread is requested before the first add: the partials were just written by other
+    // XCDs and come from beyond the L2, so a dependent second batch would double the kernel's 3 us
+    float v[2][4][8];
 #pragma unroll
-    for (int j = 0; j < 8; ++j) a[j] = 0.f;
-    // this workgroup's partials: b = blockIdx.x + 8 i; wave q takes i = q, q + 4, ...
-    for (int i0 = q; blockIdx.x + kBnL2 * i0 < nparts; i0 += 32) {
+    for (int round = 0; round < 2; ++round) {
+        const int g = round * 4 + vg;
 #pragma unroll
-        for (int j = 0; j < 8; ++j) {
-            const int b = blockIdx.x + kBnL2 * (i0 + 4 * j);
-            if (b < nparts) a[j] += part[b * 64 + idx];
+        for (int it = 0; it < 4; ++it) {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const int b = g + kBnL2 * (q + 32 * it + 4 * j);     // row g's partials: b = g + 8 i
+                v[round][it][j] = b < nparts ? part[b * 64 + idx] : 0.f;
+            }
         }
     }
-    grp[q][idx] = ((a[0] + a[1]) + (a[2] + a[3])) + ((a[4] + a[5]) + (a[6] + a[7]));
-    __syncthreads();
-    if (threadIdx.x < 64) sums[blockIdx.x * 64 + idx] = (grp[0][idx] + grp[1][idx]) + (grp[2][idx] + grp[3][idx]);
+#pragma unroll
+    for (int round = 0; round < 2; ++round) {
+        const int g = round * 4 + vg;
+        float a[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) a[j] = ((v[round][0][j] + v[round][1][j]) + v[round][2][j]) + v[round][3][j];
+        grp[vg][q][idx] = ((a[0] + a[1]) + (a[2] + a[3])) + ((a[4] + a[5]) + (a[6] + a[7]));
+        __syncthreads();
+        if (q == 0) {
+            const float r = (grp[vg][0][idx] + grp[vg][1][idx]) + (grp[vg][2][idx] + grp[vg][3][idx]);
+            rows[g][idx] = r;
+            sums[g * 64 + idx] = r;
+        }
+        __syncthreads();
+    }
 }
 
-// the consumers' read of a reduced sum: the eight second-level rows in a fixed order
-__device__ __forceinline__ float bn_sum8(const float* __restrict__ sums, int i) {
-    return ((sums[i] + sums[64 + i]) + (sums[128 + i] + sums[192 + i])) +
-           ((sums[256 + i] + sums[320 + i]) + (sums[384 + i] + sums[448 + i]));
+// the reduced sum: the eight second-level rows in a fixed order
+__device__ __forceinline__ float bn_sum8(const float (*rows)[64], int i) {
+    return ((rows[0][i] + rows[1][i]) + (rows[2][i] + rows[3][i])) + ((rows[4][i] + rows[5][i]) + (rows[6][i] + rows[7][i]));
 }
 
 // coef[0..31] = scale, coef[32..63] = shift; save[0..31] = mean, save[32..63] = invstd
-__global__ void bn_finalize_fwd_kernel(const float* __restrict__ sums, float n, const float* __restrict__ gamma,
+__global__ __launch_bounds__(1024) void bn_finalize_fwd_kernel(float* __restrict__ sums, float n, const float* __restrict__ gamma,
                                        const float* __restrict__ beta, float* __restrict__ rmean,
                                        float* __restrict__ rvar, float momentum, float eps, int training,
                                        float* __restrict__ coef, float* __restrict__ save) {
+    __shared__ float rows[kBnL2][64];
+    __shared__ float grp[4][4][64];
+    if (training) bn_rows(sums, rows, grp);
     const int c = threadIdx.x;
     if (c >= 32) return;
     float mean, var;
     if (training) {
-        mean = bn_sum8(sums, c) / n;
-        var = fmaxf(bn_sum8(sums, 32 + c) / n - mean * mean, 0.f);
+        mean = bn_sum8(rows, c) / n;
+        var = fmaxf(bn_sum8(rows, 32 + c) / n - mean * mean, 0.f);
         rmean[c] = (1.f - momentum) * rmean[c] + momentum * mean;
         rvar[c] = (1.f - momentum) * rvar[c] + momentum * var * (n / fmaxf(n - 1.f, 1.f));
     } else {
@@ -816,13 +839,16 @@ __global__ void bn_finalize_fwd_kernel(const float* __restrict__ sums, float n, 
 
 // BN backward: dy = a*g + b*y + d with a = gamma*invstd, b = -a*invstd*dgamma/n,
 // d = -a*sum_g/n - b*mean;  dgamma = invstd*(sum_gy - mean*sum_g), dbeta = sum_g.
-__global__ void bn_finalize_bwd_kernel(const float* __restrict__ sums, const float* __restrict__ save,
+__global__ __launch_bounds__(1024) void bn_finalize_bwd_kernel(float* __restrict__ sums, const float* __restrict__ save,
                                        const float* __restrict__ gamma, float n, float* __restrict__ coef3,
                                        float* __restrict__ ggamma, float* __restrict__ gbeta) {
+    __shared__ float rows[kBnL2][64];
+    __shared__ float grp[4][4][64];
+    bn_rows(sums, rows, grp);
     const int c = threadIdx.x;
     if (c >= 32) return;
     const float mean = save[c], invstd = save[32 + c];
-    const float sg = bn_sum8(sums, c), sgy = bn_sum8(sums, 32 + c);
+    const float sg = bn_sum8(rows, c), sgy = bn_sum8(rows, 32 + c);
     const float dgamma = invstd * (sgy - mean * sg);
     const float a = gamma[c] * invstd;
     const float bq = -a * invstd * dgamma / n;
@@ -923,6 +949,7 @@ __global__ __launch_bounds__(256) void block_bwd_in_kernel(const __hip_bfloat16*
         const float sm = red[0][c4][k] + red[1][c4][k] + red[2][c4][k] + red[3][c4][k];
         sums[(8 + blockIdx.x) * 64 + (k >> 3) * 32 + c4 * 8 + (k & 7)] = sm;
     }
+    if (blockIdx.x == 0 && threadIdx.x == 0) sums[kBnCountWord] = __int_as_float((int)gridDim.x);
 }
 
 // grid of the reducing kernels: every block ends in one 64-float partial, so few and fat blocks
@@ -982,7 +1009,6 @@ extern "C" int sp_conv3x5(const void* in, const void* in2, const float* coef, in
     else if (in_mode == IN_BNBWD && epi_mode == EPI_ADD) SP_CONV_LAUNCH(IN_BNBWD, EPI_ADD);
     else return fail(SP_EINVAL, "sp_conv3x5: unsupported mode pair (%d, %d)", in_mode, epi_mode);
 #undef SP_CONV_LAUNCH
-    if (bn_sums) hipLaunchKernelGGL(bn_sum_parts_kernel, dim3(kBnL2), dim3(256), 0, s, bn_sums, (int)grid.x);
     return check_launch("conv3x5_kernel");
 }
 
@@ -1043,7 +1069,6 @@ extern "C" int sp_bn_stats(const void* y, int64_t npos, float* sums, void* strea
     const int nb = reduce_blocks(npos * 4);
     hipLaunchKernelGGL((bn_reduce_kernel<0>), dim3(nb), dim3(256), 0, s, (const bf16*)y,
                        (const bf16*)nullptr, npos, sums);
-    hipLaunchKernelGGL(bn_sum_parts_kernel, dim3(kBnL2), dim3(256), 0, s, sums, nb);
     return check_launch("bn_reduce_kernel<0>");
 }
 
@@ -1053,24 +1078,23 @@ extern "C" int sp_bn_bwd_reduce(const void* g, const void* y, int64_t npos, floa
     const int nb = reduce_blocks(npos * 4);
     hipLaunchKernelGGL((bn_reduce_kernel<1>), dim3(nb), dim3(256), 0, s, (const bf16*)g,
                        (const bf16*)y, npos, sums);
-    hipLaunchKernelGGL(bn_sum_parts_kernel, dim3(kBnL2), dim3(256), 0, s, sums, nb);
     return check_launch("bn_reduce_kernel<1>");
 }
 
-extern "C" int sp_bn_finalize_fwd(const float* sums, int64_t npos, const float* gamma, const float* beta,
+extern "C" int sp_bn_finalize_fwd(float* sums, int64_t npos, const float* gamma, const float* beta,
                                   float* rmean, float* rvar, float momentum, float eps, int training,
                                   float* coef, float* save, void* stream) {
     SP_CHECK_ARG(gamma && beta && rmean && rvar && coef && save && (sums || !training),
                  "sp_bn_finalize_fwd: null pointer");
-    hipLaunchKernelGGL(bn_finalize_fwd_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, sums, (float)npos,
+    hipLaunchKernelGGL(bn_finalize_fwd_kernel, dim3(1), dim3(1024), 0, (hipStream_t)stream, sums, (float)npos,
                        gamma, beta, rmean, rvar, momentum, eps, training, coef, save);
     return check_launch("bn_finalize_fwd_kernel");
 }
 
-extern "C" int sp_bn_finalize_bwd(const float* sums, const float* save, const float* gamma, int64_t npos,
+extern "C" int sp_bn_finalize_bwd(float* sums, const float* save, const float* gamma, int64_t npos,
                                   float* coef3, float* ggamma, float* gbeta, void* stream) {
     SP_CHECK_ARG(sums && save && gamma && coef3 && ggamma && gbeta, "sp_bn_finalize_bwd: null pointer");
-    hipLaunchKernelGGL(bn_finalize_bwd_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, sums, save, gamma,
+    hipLaunchKernelGGL(bn_finalize_bwd_kernel, dim3(1), dim3(1024), 0, (hipStream_t)stream, sums, save, gamma,
                        (float)npos, coef3, ggamma, gbeta);
     return check_launch("bn_finalize_bwd_kernel");
 }
@@ -1104,6 +1128,5 @@ extern "C" int sp_block_bwd_in(const void* gz, const void* z, int64_t zsb, int64
     else
         hipLaunchKernelGGL((block_bwd_in_kernel<false>), dim3(nb), dim3(256), 0, s, (const bf16*)gz, (const bf16*)z, zs,
                            (const bf16*)y2, B, F, T, (bf16*)gpre, sums);
-    hipLaunchKernelGGL(bn_sum_parts_kernel, dim3(kBnL2), dim3(256), 0, s, sums, nb);
     return check_launch("block_bwd_in_kernel");
 }

@@ -455,8 +455,8 @@ def test_conv_kernels_individually(cuda, shape):
     # --- BN backward reduce / block backward entry
     from speech_amd._lib import BN_SUMS_WORDS
     sums_buf = torch.empty(BN_SUMS_WORDS, device=cuda)
-    sums = sums_buf          # result = sum of the first eight rows of 64
-    red = lambda t: t[:512].view(8, 64).sum(0)
+    sums = sums_buf          # per-workgroup partials + their count; sp_bn_finalize_* adds them up
+    red = _bn_total
     check(lib().sp_bn_bwd_reduce(ptr(gten), ptr(yten), B * Fq * T, ptr(sums), stream_ptr()), "reduce")
     ref_s = torch.cat([gten.float().sum((0, 1, 2)), (gten.float() * yten.float()).sum((0, 1, 2))])
     assert float((red(sums) - ref_s).abs().max()) <= 2e-3 * float(ref_s.abs().max()) + 1e-2
@@ -639,6 +639,13 @@ def test_mel_int16_pcm_equals_float_path(cuda):
     assert torch.equal(e, data.featurize([pcm[0].float() / 32768.0, pcm[1].float() / 32768.0]))
 
 
+def _bn_total(t):
+    """The reduction a producer left in a `sums` buffer: its per-workgroup partials (count in the last word)."""
+    n = int(t[512 + 1024 * 64: 512 + 1024 * 64 + 1].view(torch.int32))
+    assert 1 <= n <= 1024
+    return t[512: 512 + 64 * n].view(n, 64).double().sum(0).float()
+
+
 def test_conv_fused_bn_sums_are_reproducible(cuda):
     """The statistics fused into the convolution epilogue equal sp_bn_stats of its output, and two
     launches give the same BITS (per-workgroup partials summed in a fixed order, no float atomics)."""
@@ -653,12 +660,29 @@ def test_conv_fused_bn_sums_are_reproducible(cuda):
     s2 = torch.full((BN_SUMS_WORDS,), float("nan"), device=cuda)     # nothing relies on a zeroed buffer
     y1 = cs._conv(x, None, None, cs.IN_ID, cs._pack(w, 0), bias, None, None, cs.EPI_NONE, B, F, T, s1)
     y2 = cs._conv(x, None, None, cs.IN_ID, cs._pack(w, 0), bias, None, None, cs.EPI_NONE, B, F, T, s2)
-    assert torch.equal(y1, y2) and torch.equal(s1[:512], s2[:512])
+    n = int(s1[512 + 1024 * 64: 512 + 1024 * 64 + 1].view(torch.int32))
+    assert torch.equal(y1, y2) and torch.equal(s1[512: 512 + 64 * n], s2[512: 512 + 64 * n])
+    assert torch.equal(s1[512 + 1024 * 64: 513 + 1024 * 64].view(torch.int32), s2[512 + 1024 * 64: 513 + 1024 * 64].view(torch.int32))
     s3 = torch.empty(BN_SUMS_WORDS, device=cuda)
     check(lib().sp_bn_stats(ptr(y1), B * F * T, ptr(s3), stream_ptr()), "sp_bn_stats")
     ref = torch.cat([y1.float().reshape(-1, 32).sum(0), y1.float().reshape(-1, 32).pow(2).sum(0)])
-    assert torch.allclose(s1[:512].view(8, 64).sum(0), ref, rtol=1e-4, atol=1e-2)
-    assert torch.allclose(s3[:512].view(8, 64).sum(0), ref, rtol=1e-4, atol=1e-2)
+    assert torch.allclose(_bn_total(s1), ref, rtol=1e-4, atol=1e-2)
+    assert torch.allclose(_bn_total(s3), ref, rtol=1e-4, atol=1e-2)
+    # the finaliser adds the partials into the eight rows in a fixed order: same bits on both buffers, and the
+    # coefficients are those of torch's batch statistics
+    outs = []
+    for sb in (s1, s2):
+        gamma, beta = torch.ones(32, device=cuda), torch.zeros(32, device=cuda)
+        rm, rv = torch.zeros(32, device=cuda), torch.ones(32, device=cuda)
+        coef, save = torch.empty(64, device=cuda), torch.empty(64, device=cuda)
+        check(lib().sp_bn_finalize_fwd(ptr(sb), B * F * T, ptr(gamma), ptr(beta), ptr(rm), ptr(rv), 0.1, 1e-5, 1,
+                                       ptr(coef), ptr(save), stream_ptr()), "sp_bn_finalize_fwd")
+        outs.append((coef, save, sb[:512].clone()))
+    assert all(torch.equal(a, b) for a, b in zip(outs[0], outs[1]))
+    assert torch.allclose(outs[0][2].view(8, 64).sum(0), ref, rtol=1e-4, atol=1e-2)
+    yf = y1.float().reshape(-1, 32)
+    assert torch.allclose(outs[0][1][:32], yf.mean(0), rtol=1e-3, atol=1e-3)
+    assert torch.allclose(outs[0][1][32:], (yf.var(0, unbiased=False) + 1e-5).rsqrt(), rtol=2e-3)
 
 
 # =============================================================================== hand-written GEMM

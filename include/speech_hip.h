@@ -233,9 +233,9 @@ int sp_adam_step_f32(float* p, const float* g, float* m, float* v, int64_t n, fl
  *   activation, are bit-reproducible.
  * sp_conv3x5_wgrad: gw[32][32][3][5] += sum_pos dy[pos][co] * a[pos + tap][ci], with
  *   a = a_src (a_mode 0) or relu(BN(a_src)) (a_mode 1), dy = g_coef affine of (g, y) as in_mode 2.
- *   gwp_ws: 8*15*32*32 f32 workspace, one partial copy per XCD.  Contract: the caller zeroes it ONCE (when it
- *   allocates it); every successful call leaves it zeroed again (the unpack kernel clears what it has read), so
- *   back-to-back calls need no fill.  After a failed call, or if two streams share one workspace, zero it again.
+ *   gwp_ws: workspace of SP_CONV_WGRAD_WS_WORDS floats (one 15*32*32 slab per persistent workgroup, at most
+ *   SP_CONV_WGRAD_SLABS).  Nothing in it has to be zero: every slab that is read has been written by the same
+ *   call, and the slabs are added in a fixed order (no float atomics: gw is bit-reproducible).
  * sp_conv_stem_fwd/bwd: Conv2d(1,32,3,stride 2,pad 1) on the f32 spectrogram [B][Fin][Tin] ->
  *   [B][F][T][32], F = (Fin-1)/2+1, T = (Tin-1)/2+1; bwd accumulates gw[32*9], gbias[32].
  * sp_bn_stats: (sum y | sum y^2) per channel, as per-workgroup partials in sums (see above).
@@ -248,6 +248,8 @@ int sp_adam_step_f32(float* p, const float* g, float* m, float* v, int64_t n, fl
  * sp_block_bwd_in: gpre = gz * [z > 0] (gz, z in that layout); sums = (sum gpre, sum gpre*y2).
  * --------------------------------------------------------------------------------------- */
 #define SP_BN_SUMS_WORDS (8 * 64 + 1024 * 64 + 64)
+#define SP_CONV_WGRAD_SLABS 512
+#define SP_CONV_WGRAD_WS_WORDS (SP_CONV_WGRAD_SLABS * 15 * 32 * 32)
 int sp_conv_pack_w(const float* w, int bwd_data, void* wpack, void* stream);
 int sp_conv3x5(const void* in, const void* in2, const float* coef, int in_mode, const void* wpack,
                const float* bias, const void* epi_src, const float* epi_coef, int epi_mode, int B,

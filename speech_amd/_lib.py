@@ -11,6 +11,7 @@ LIB_PATH = os.path.join(_HERE, "libspeech_hip.so")
 
 SP_F32, SP_F16, SP_BF16 = 0, 1, 2
 SUMSQ_WORDS = 1025   # SP_SUMSQ_WORDS of include/speech_hip.h
+CONV_WGRAD_WS_WORDS = 512 * 15 * 32 * 32   # SP_CONV_WGRAD_WS_WORDS: one slab per persistent workgroup
 BN_SUMS_WORDS = 8 * 64 + 1024 * 64 + 64   # SP_BN_SUMS_WORDS: [8][64] rows, per-workgroup partials, their count
 
 _c = ctypes

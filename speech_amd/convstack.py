@@ -10,7 +10,7 @@ BatchNorm-backward affine map the same way.
 """
 import torch
 
-from ._lib import BN_SUMS_WORDS, check, lib, ptr, stream_ptr
+from ._lib import BN_SUMS_WORDS, CONV_WGRAD_WS_WORDS, check, lib, ptr, stream_ptr
 
 IN_ID, IN_BNRELU, IN_BNBWD = 0, 1, 2
 EPI_NONE, EPI_MASK, EPI_ADD = 0, 1, 2
@@ -39,10 +39,10 @@ _wgrad_ws = {}
 
 
 def _wgrad_workspace(dev):
-    """sp_conv3x5_wgrad's scratch: zeroed once here, handed back zeroed by every call."""
+    """sp_conv3x5_wgrad's scratch (one slab per persistent workgroup; nothing in it needs to be zero)."""
     key = dev.index if dev.index is not None else torch.cuda.current_device()
     if key not in _wgrad_ws:
-        _wgrad_ws[key] = torch.zeros(8 * 15 * 32 * 32, dtype=torch.float32, device=dev)
+        _wgrad_ws[key] = torch.empty(CONV_WGRAD_WS_WORDS, dtype=torch.float32, device=dev)
     return _wgrad_ws[key]
 
 

@@ -321,64 +321,62 @@ __global__ __launch_bounds__(256, 2) void conv3x5_kernel(
 // ---------------------------------------------------------------------------------------------
 // conv3x5 weight gradient
 // ---------------------------------------------------------------------------------------------
-// Row pitch (positions) of the transposed LDS images and the per-channel-group skew: channel c's row
-// starts at c * kWR + (c / 8) * kWSkew.  With 192-byte rows and a 16-byte skew both the staging
-// ds_write_b16 (lanes = 8 positions x 4 channel groups) and the fragment ds_read_b128 are free of bank
-// conflicts; with plain 144-byte rows the four channel groups of a store shared one bank (4-way).
-constexpr int kWR = 96, kWSkew = 8;
-
-// 16 bytes at bf16-element offset E (0..4) of a 32-byte window held as two uint4
-template <int E>
-__device__ __forceinline__ uint4 window16(const uint4& lo, const uint4& hi) {
-    const uint32_t w[8] = {lo.x, lo.y, lo.z, lo.w, hi.x, hi.y, hi.z, hi.w};
-    uint4 o;
-    if (E % 2 == 0) {
-        o.x = w[E / 2]; o.y = w[E / 2 + 1]; o.z = w[E / 2 + 2]; o.w = w[E / 2 + 3];
-    } else {
-        o.x = __builtin_amdgcn_alignbit(w[E / 2 + 1], w[E / 2], 16);
-        o.y = __builtin_amdgcn_alignbit(w[E / 2 + 2], w[E / 2 + 1], 16);
-        o.z = __builtin_amdgcn_alignbit(w[E / 2 + 3], w[E / 2 + 2], 16);
-        o.w = __builtin_amdgcn_alignbit(w[E / 2 + 4], w[E / 2 + 3], 16);
-    }
-    return o;
-}
-
+// Operands: D[co][ci] (per tap) += sum_pos dy[pos][co] * a[pos + tap][ci], K = positions.  The MFMA wants 8
+// consecutive k (positions) per lane while memory holds consecutive channels per position.  The rows are staged
+// in LDS exactly as they lie in memory -- [position][32 channels], one 16-byte store per thread, the producers'
+// BatchNorm transforms applied in registers on the way -- and the fragments are read with ds_read_b64_tr_b16,
+// which hands each lane one COLUMN (channel) of a 4 (positions) x 16 (channels) block: two reads = 8 positions.
+// A tap's kw shift is an address offset of whole 64-byte rows, so all five taps read the same image.
+// (The first version transposed while staging -- sixteen 16-bit LDS stores per thread and row -- and shifted
+// 32-byte windows in registers: 190 vector instructions per row and wave against 12 MFMAs.)
+//
 // A workgroup is kWG independent groups of five waves (one (image, row range, 64-position chunk) item
-// each) that meet again only at the end: the groups' accumulators are added through LDS and ONE of
-// them issues the float atomics.  The atomics are what this buys: every workgroup result is 15 x 32 x 32
-// dword atomics, the L2 executes them one dword at a time, and with one item per workgroup they were a
-// third of the kernel's time.
+// each; wave = kw tap, three kh accumulators) that meet again only at the end: the groups' accumulators are
+// added through LDS and ONE of them issues the float atomics.  The atomics are what this buys: every workgroup
+// result is 15 x 32 x 32 dword atomics, the L2 executes them one dword at a time, and with one item per
+// workgroup they were a third of the kernel's time.
 constexpr int kWG = 3;
+typedef short wg_s16x4 __attribute__((ext_vector_type(4)));
+typedef short wg_s16x8 __attribute__((ext_vector_type(8)));
+
+// 8 consecutive positions (rows of 32 channels = 64 bytes) of this lane's channel, from LDS byte address `addr`
+// (the lane's row 8 kg + qq, 8-byte piece p of channel half hm: see the caller)
+__device__ __forceinline__ bf16x8 wgrad_frag(uint32_t addr) {
+    typedef __attribute__((address_space(3))) wg_s16x4* lp;
+    const wg_s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lp)(uintptr_t)addr);
+    const wg_s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lp)(uintptr_t)(addr + 4 * 64));
+    const wg_s16x8 v = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+    return __builtin_bit_cast(bf16x8, v);
+}
 
 template <int A_MODE>
 __global__ __launch_bounds__(320 * kWG) void conv3x5_wgrad_kernel(
     const __hip_bfloat16* __restrict__ asrc, const float* __restrict__ acoef,
     const __hip_bfloat16* __restrict__ g, const __hip_bfloat16* __restrict__ y,
     const float* __restrict__ gcoef, int B, int F, int T, int fsplit, int ntc, float* __restrict__ gwp) {
-    // dy row: ONE transposed copy [co][68 positions, origin t0-2]; the five kw taps read the same
-    // aligned 32-byte windows and shift them in registers (v_alignbit), instead of five shifted copies
-    constexpr int kGys = 32 * kWR, kAring = 3 * 32 * kWR;          // bf16 elements per group
-    __shared__ __attribute__((aligned(16))) __hip_bfloat16 smem[kWG * (kGys + kAring)];
-    static_assert(sizeof(__hip_bfloat16) * kWG * (kGys + kAring) >= sizeof(float) * (kWG - 1) * 5 * 16 * 64,
+    // per group: four activation rows [64 positions][32] (rows f-1, f, f+1 in use, f+2 being written) and two
+    // dy rows [68 positions, origin t0-2][32] (row f in use, f+1 being written): one barrier per row
+    constexpr int kARow = 64 * 32, kGRow = 68 * 32, kASlots = 4, kGSlots = 2;
+    constexpr int kGrp = kASlots * kARow + kGSlots * kGRow;          // bf16 elements per group (24.5 KB)
+    __shared__ __attribute__((aligned(256))) __hip_bfloat16 smem[kWG * kGrp];
+    static_assert(sizeof(__hip_bfloat16) * kWG * kGrp >= sizeof(float) * (kWG - 1) * 5 * 16 * 64,
                   "the staging buffers double as the end-of-kernel reduction buffer");
     const int grp = threadIdx.x / 320, tid = threadIdx.x - grp * 320;   // 320 = 5 waves: groups are wave-aligned
-    __hip_bfloat16* gys = smem + grp * (kGys + kAring);
-    __hip_bfloat16* aring = gys + kGys;
+    __hip_bfloat16* aring = smem + grp * kGrp;
+    __hip_bfloat16* gring = aring + kASlots * kARow;
     const int lane = tid & 63, wave = tid >> 6;
     const int r = lane & 31, h = lane >> 5;
-    // item = (image b, row range fs, position chunk tc); a group past the last item runs empty rows
-    const int item = blockIdx.x * kWG + grp;
-    const bool live = item < ntc * B * fsplit;
-    const int tc = item % ntc, bf = min(item / ntc, B * fsplit - 1);
-    const int t0 = tc * 64;
-    const int b = bf / fsplit, fs = bf % fsplit;
-    const int fper = (F + fsplit - 1) / fsplit;
-    const int fa = fs * fper, fb = live ? min(F, fa + fper) : fa;
-    const int64_t img = (int64_t)b * F * T;
+    // item = (image b, row range fs, position chunk tc); a group past the last item runs empty rows.  The
+    // workgroups are persistent: group (blockIdx.x, grp) takes items blockIdx.x * kWG + grp + k * gridDim.x * kWG
+    // and keeps accumulating in the same registers, so there is one result per workgroup however large the batch
+    const int nitems = ntc * B * fsplit, fper = (F + fsplit - 1) / fsplit;
+    const int niter = (nitems + (int)gridDim.x * kWG - 1) / ((int)gridDim.x * kWG);
+    bool live = false;
+    int t0 = 0, fa = 0, fb = 0;
+    int64_t img = 0;
     const int ch4 = tid & 3;
 
-    // per-channel coefficients live in LDS (40 VGPRs otherwise: the kernel must stay under 128 to keep
-    // four waves per SIMD, which is what hides the per-row HBM latency)
+    // per-channel coefficients live in LDS (40 VGPRs otherwise)
     __shared__ __attribute__((aligned(16))) float scoef[5][32];   // ga gb gd a0 a1
     if (threadIdx.x < 96) scoef[tid >> 5][tid & 31] = gcoef[tid];
     else if (threadIdx.x < 160) scoef[3 + ((tid - 96) >> 5)][tid & 31] = (A_MODE == IN_BNRELU) ? acoef[tid - 96] : ((tid < 128) ? 1.f : 0.f);
@@ -389,8 +387,8 @@ __global__ __launch_bounds__(320 * kWG) void conv3x5_wgrad_kernel(
     const float* a0 = scoef[3] + ch4 * 8;
     const float* a1 = scoef[4] + ch4 * 8;
 
-    // global -> registers (issued one f-row ahead) and registers -> LDS (transposed) are split so
-    // that a row's HBM latency hides behind the previous row's MFMAs
+    // global -> registers (issued PF rows ahead) and registers -> LDS are split so that a row's HBM latency
+    // hides behind the previous rows' MFMAs
     struct RowRegs { uint4 a, g, y; bool aok, gok; };
     auto load_row = [&](int frow_a, int frow_g, RowRegs& rr) {
         rr.a = rr.g = rr.y = make_uint4(0, 0, 0, 0);
@@ -405,31 +403,27 @@ __global__ __launch_bounds__(320 * kWG) void conv3x5_wgrad_kernel(
             rr.y = *reinterpret_cast<const uint4*>(y + off);
         }
     };
-    auto store_a = [&](int frow, const RowRegs& rr) {   // activation row -> ring slot (frow + 3) % 3, [ci][pos]
+    auto store_a = [&](int frow, const RowRegs& rr) {   // activation row -> slot frow mod 4, [pos][ci]
         if (tid < 256) {
-            const int pos = tid >> 2;
-            float x[8];
-            unpack8(rr.a, x);
+            uint4 o = rr.a;                              // zeros where the row or the position is padding
             if (A_MODE == IN_BNRELU) {
+                float x[8];
+                unpack8(rr.a, x);
 #pragma unroll
                 for (int j = 0; j < 8; ++j) x[j] = rr.aok ? fmaxf(0.f, a0[j] * x[j] + a1[j]) : 0.f;
+                o = pack8(x);
             }
-            __hip_bfloat16* dst = aring + ((frow + 3) % 3) * 32 * kWR + (ch4 * 8) * kWR + ch4 * kWSkew + pos;
-#pragma unroll
-            for (int j = 0; j < 8; ++j) dst[j * kWR] = __float2bfloat16(x[j]);
+            *reinterpret_cast<uint4*>(aring + ((frow + kASlots) % kASlots) * kARow + tid * 8) = o;
         }
     };
-    auto store_g = [&](const RowRegs& rr) {   // dy row (BN-backward affine applied) -> [co][idx]
+    auto store_g = [&](int frow, const RowRegs& rr) {   // dy row (BN-backward affine applied) -> slot frow mod 2, [idx][co]
         if (tid < 272) {
-            const int idx = tid >> 2;
             float x[8], yv[8];
             unpack8(rr.g, x);
             unpack8(rr.y, yv);
 #pragma unroll
             for (int j = 0; j < 8; ++j) x[j] = rr.gok ? ga[j] * x[j] + gb[j] * yv[j] + gd[j] : 0.f;
-            __hip_bfloat16* dst = gys + (ch4 * 8) * kWR + ch4 * kWSkew + idx;
-#pragma unroll
-            for (int j = 0; j < 8; ++j) dst[j * kWR] = __float2bfloat16(x[j]);
+            *reinterpret_cast<uint4*>(gring + (frow & 1) * kGRow + tid * 8) = pack8(x);
         }
     };
 
@@ -439,91 +433,117 @@ __global__ __launch_bounds__(320 * kWG) void conv3x5_wgrad_kernel(
 #pragma unroll
         for (int q = 0; q < 16; ++q) acc[k][q] = 0.f;
 
-    // rows are requested PF iterations ahead (an iteration is ~0.5 us of LDS + MFMA work, an HBM
-    // round trip 2+ us): q[0] is the row being stored now, q[PF-1] the one just requested
-    constexpr int PF = 1;
-    RowRegs q[PF];
-    {
-        RowRegs p0, p1;
-        load_row(fa - 1, -1, p0);
-        load_row(fa, -1, p1);
-        store_a(fa - 1, p0);
-        store_a(fa, p1);
-    }
+    // fragment address of this lane: a 16-lane group reads a 4 (positions) x 16 (channels) block, lane (qq, p)
+    // supplies row qq's 8-byte piece p and receives column 4 qq + p; hm = channel half, kg = k group of the MFMA
+    const int li = lane & 15, qq = li >> 2, pp = li & 3, hm = (lane >> 4) & 1, kg = lane >> 5;
+    const uint32_t lane_off = (uint32_t)((8 * kg + qq) * 64 + hm * 32 + pp * 8);
+    typedef __attribute__((address_space(3))) void* lds_vp;
+    const uint32_t a_base = (uint32_t)(uintptr_t)(lds_vp)aring + lane_off;
+    // tap kw = wave reads dy at row offset 4 - kw of the 68-position window
+    const uint32_t g_base = (uint32_t)(uintptr_t)(lds_vp)gring + lane_off + (uint32_t)(4 - wave) * 64;
+
+    constexpr int PF = 2;      // rows in flight per thread; 3 pushes the kernel past 128 VGPRs (four waves per SIMD are needed for the 15-wave workgroup): 60 -> 68 us
+    for (int iter = 0; iter < niter; ++iter) {
+        const int item = (iter * (int)gridDim.x + (int)blockIdx.x) * kWG + grp;
+        live = item < nitems;
+        const int tc = item % ntc, bf = min(item / ntc, B * fsplit - 1);
+        t0 = tc * 64;
+        const int b = bf / fsplit, fs = bf % fsplit;
+        fa = fs * fper;
+        fb = live ? min(F, fa + fper) : fa;
+        img = (int64_t)b * F * T;
+        RowRegs q[PF];
+        {
+            RowRegs p0, p1, p2;
+            load_row(fa - 1, -1, p0);
+            load_row(fa, -1, p1);
+            load_row(fa + 1, fa < fb ? fa : -1, p2);
 #pragma unroll
-    for (int i = 0; i < PF; ++i) load_row(fa + 1 + i, fa + i < fb ? fa + i : -1, q[i]);
-    for (int f = fa; f < fa + fper; ++f) {   // every group runs fper rows (the barriers are the workgroup's): rows past fb are zeros
-        store_a(f + 1, q[0]);
-        store_g(q[0]);
-#pragma unroll
-        for (int i = 0; i + 1 < PF; ++i) q[i] = q[i + 1];
-        load_row(f + 1 + PF, f + PF < fb ? f + PF : -1, q[PF - 1]);
-        __syncthreads();
-#pragma unroll
-        for (int ks = 0; ks < 4; ++ks) {
-            const uint4* wp = reinterpret_cast<const uint4*>(gys + r * kWR + (r >> 3) * kWSkew + ks * 16 + 8 * h);
-            const uint4 lo = wp[0], hi = wp[1];
-            // tap kw = wave reads dy at column offset 4 - kw of the window
-            uint4 av;
-            switch (wave) {
-                case 0: av = window16<4>(lo, hi); break;
-                case 1: av = window16<3>(lo, hi); break;
-                case 2: av = window16<2>(lo, hi); break;
-                case 3: av = window16<1>(lo, hi); break;
-                default: av = window16<0>(lo, hi); break;
-            }
-            const bf16x8 A = __builtin_bit_cast(bf16x8, av);
-#pragma unroll
-            for (int kh = 0; kh < 3; ++kh) {
-                const int slot = (f + kh + 2) % 3;  // row f + kh - 1
-                const bf16x8 Bv = __builtin_bit_cast(
-                    bf16x8, *reinterpret_cast<const uint4*>(aring + (slot * 32 + r) * kWR + (r >> 3) * kWSkew + ks * 16 + 8 * h));
-                acc[kh] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A, Bv, acc[kh], 0, 0, 0);
-            }
+            for (int i = 0; i < PF; ++i) load_row(fa + 2 + i, fa + 1 + i < fb ? fa + 1 + i : -1, q[i]);
+            store_a(fa - 1, p0);
+            store_a(fa, p1);
+            store_a(fa + 1, p2);
+            store_g(fa, p2);
         }
         __syncthreads();
+        for (int f = fa; f < fa + fper; ++f) {   // every group runs fper rows (the barriers are the workgroup's): rows past fb are zeros
+            // rows of the NEXT iteration: their slots were last read in the previous iteration
+            store_a(f + 2, q[0]);
+            store_g(f + 1, q[0]);
+#pragma unroll
+            for (int i = 0; i + 1 < PF; ++i) q[i] = q[i + 1];
+            load_row(f + 2 + PF, f + 1 + PF < fb ? f + 1 + PF : -1, q[PF - 1]);
+            const uint32_t gs = g_base + (uint32_t)((f & 1) * kGRow * 2);
+#pragma unroll
+            for (int ks = 0; ks < 4; ++ks) {
+                const bf16x8 A = wgrad_frag(gs + ks * 16 * 64);
+#pragma unroll
+                for (int kh = 0; kh < 3; ++kh) {
+                    const int slot = (f + kh - 1 + kASlots) % kASlots;
+                    const bf16x8 Bv = wgrad_frag(a_base + (uint32_t)(slot * kARow * 2 + ks * 16 * 64));
+                    acc[kh] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A, Bv, acc[kh], 0, 0, 0);
+                }
+            }
+            __syncthreads();
+        }
     }
-    // D[row = co][col = ci]: lane = ci, registers = co 8g + 4h + i; gwp[copy][tap][co][ci].
+    // D[row = co][col = ci]: lane = ci, registers = co 8g + 4h + i; gwp[workgroup][tap][co][ci].
     // Groups 1 .. kWG-1 hand their accumulators to group 0 through LDS (the staging buffers are free:
-    // the loop ended in a barrier), one kh plane at a time, added in a fixed order.
-    // Workgroups are dealt round-robin to the 8 XCDs by linear id: with one copy per residue mod 8
-    // every atomic stays inside one XCD's L2 instead of being a cross-XCD (memory-side) atomic.
+    // the loop ended in a barrier), one kh plane at a time, added in a fixed order, and group 0 STORES the
+    // workgroup's sum to the workgroup's own slab: no float atomics (the L2 executes those one dword at a time --
+    // 15 360 per workgroup, all arriving when the single round of workgroups ends), and the unpack kernel's
+    // fixed-order sum over the slabs makes the weight gradient bit-reproducible.
     float* rbuf = reinterpret_cast<float*>(smem);   // [kWG-1][5 waves][16][64]
-    float* gcopy = gwp + (size_t)(blockIdx.x & 7) * (15 * 32 * 32);
+    float* slab = gwp + (size_t)blockIdx.x * (15 * 32 * 32);
 #pragma unroll
     for (int kh = 0; kh < 3; ++kh) {
         if (grp > 0) {
 #pragma unroll
-            for (int q = 0; q < 16; ++q) rbuf[(((grp - 1) * 5 + wave) * 16 + q) * 64 + lane] = acc[kh][q];
+            for (int q2 = 0; q2 < 16; ++q2) rbuf[(((grp - 1) * 5 + wave) * 16 + q2) * 64 + lane] = acc[kh][q2];
         }
         __syncthreads();
         if (grp == 0) {
             const int tap = kh * 5 + wave;
 #pragma unroll
-            for (int q = 0; q < 16; ++q) {
-                float v = acc[kh][q];
+            for (int q2 = 0; q2 < 16; ++q2) {
+                float v = acc[kh][q2];
 #pragma unroll
-                for (int o = 0; o < kWG - 1; ++o) v += rbuf[((o * 5 + wave) * 16 + q) * 64 + lane];
-                const int co = 8 * (q >> 2) + 4 * h + (q & 3);
-                atomicAdd(gcopy + (tap * 32 + co) * 32 + r, v);
+                for (int o = 0; o < kWG - 1; ++o) v += rbuf[((o * 5 + wave) * 16 + q2) * 64 + lane];
+                const int co = 8 * (q2 >> 2) + 4 * h + (q2 & 3);
+                slab[(tap * 32 + co) * 32 + r] = v;
             }
         }
         __syncthreads();
     }
 }
 
-__global__ void conv_wgrad_unpack_kernel(float* __restrict__ gwp, float* __restrict__ gw) {
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;  // over [co][ci][kh][kw]
-    if (i >= 32 * 32 * 15) return;
-    const int tap = i % 15, ci = (i / 15) % 32, co = i / (15 * 32);
+// gw[co][ci][kh][kw] += sum over the workgroups' slabs, in a fixed order.  A workgroup of 16 waves owns 64
+// consecutive outputs; wave w adds slabs w, w + 16, ... (every load of a thread is in flight before the first
+// add: the slabs come from beyond the L2 and a second dependent batch would double the kernel's time), then the
+// sixteen partial sums are added through LDS in a fixed order.
+__global__ __launch_bounds__(1024) void conv_wgrad_unpack_kernel(const float* __restrict__ gwp, int nslabs, float* __restrict__ gw) {
+    constexpr int NL = SP_CONV_WGRAD_SLABS / 16;
+    __shared__ float part[16][64];
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const int i = blockIdx.x * 64 + lane;                 // over [tap][co][ci]: a wave reads 256 contiguous bytes of a slab
+    float v[NL];
+#pragma unroll
+    for (int j = 0; j < NL; ++j) {
+        const int c = w + 16 * j;
+        v[j] = c < nslabs ? gwp[(size_t)c * (15 * 32 * 32) + i] : 0.f;
+    }
     float sum = 0.f;
 #pragma unroll
-    for (int c = 0; c < 8; ++c) {
-        float* p = gwp + c * (15 * 32 * 32) + (tap * 32 + co) * 32 + ci;
-        sum += *p;
-        *p = 0.f;           // the workspace is handed back zeroed: the next launch needs no fill
+    for (int j = 0; j < NL; ++j) sum += v[j];
+    part[w][lane] = sum;
+    __syncthreads();
+    if (w == 0) {
+        float t = 0.f;
+#pragma unroll
+        for (int k = 0; k < 16; ++k) t += part[k][lane];
+        const int ci = i & 31, co = (i >> 5) & 31, tap = i >> 10;
+        gw[(co * 32 + ci) * 15 + tap] += t;
     }
-    gw[i] += sum;
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -1023,7 +1043,10 @@ extern "C" int sp_conv3x5_wgrad(const void* a_src, const float* a_coef, int a_mo
     const int fsplit = F >= 8 ? 2 : 1, ntc = (T + 63) / 64;
     const int64_t items = (int64_t)ntc * B * fsplit;
     SP_CHECK_ARG(items < ((int64_t)1 << 30), "sp_conv3x5_wgrad: too many work items");
-    dim3 grid((unsigned)((items + kWG - 1) / kWG)), blk(320 * kWG);
+    // persistent workgroups, one slab of the workspace each: at most SP_CONV_WGRAD_SLABS of them
+    const int64_t want = (items + kWG - 1) / kWG;
+    const int nwg = (int)(want < SP_CONV_WGRAD_SLABS ? want : SP_CONV_WGRAD_SLABS);
+    dim3 grid((unsigned)nwg), blk(320 * kWG);
     if (a_mode == IN_ID)
         hipLaunchKernelGGL((conv3x5_wgrad_kernel<IN_ID>), grid, blk, 0, s, (const bf16*)a_src, a_coef,
                            (const bf16*)g, (const bf16*)y, g_coef, B, F, T, fsplit, ntc, gwp_ws);
@@ -1032,7 +1055,7 @@ extern "C" int sp_conv3x5_wgrad(const void* a_src, const float* a_coef, int a_mo
                            (const bf16*)g, (const bf16*)y, g_coef, B, F, T, fsplit, ntc, gwp_ws);
     rc = check_launch("conv3x5_wgrad_kernel");
     if (rc) return rc;
-    hipLaunchKernelGGL(conv_wgrad_unpack_kernel, dim3(60), dim3(256), 0, s, gwp_ws, gw);
+    hipLaunchKernelGGL(conv_wgrad_unpack_kernel, dim3(15 * 32 * 32 / 64), dim3(1024), 0, s, gwp_ws, nwg, gw);
     return check_launch("conv_wgrad_unpack_kernel");
 }
 

@@ -135,23 +135,22 @@ __global__ __launch_bounds__(256, 2) void conv3x5_kernel(
         img = (int64_t)(rest / nfy) * F * T;
     };
     auto load_strip = [&](int tl) {   // global -> registers, nothing waits on it here
+        // branch-free: every lane loads from a clamped (valid) address and `ok` decides later whether the value
+        // or the zero padding is stored -- an exec-mask branch per guarded load cost ~30 cycles apiece
         int t0, f0;
         int64_t img;
-        decode(tl, t0, f0, img);
+        decode(min(tl, ntiles - 1), t0, f0, img);
 #pragma unroll
         for (int it = 0; it < NIT; ++it) {
-            const int id = tid + it * 256;
+            const int id = min(tid + it * 256, kRows * kPW * 4 - 1);
             const int row = id / (kPW * 4);
             const int pos = (id - row * (kPW * 4)) >> 2;
             const int f = f0 - 1 + row, t = t0 - 2 + pos;
-            ok[it] = tl < ntiles && id < kRows * kPW * 4 && f >= 0 && f < F && t >= 0 && t < T;
-            v[it] = make_uint4(0, 0, 0, 0);
-            v2[it] = make_uint4(0, 0, 0, 0);
-            if (ok[it]) {
-                const int64_t off = ((img + (int64_t)f * T + t) * kC + ch4 * 8);
-                v[it] = *reinterpret_cast<const uint4*>(in + off);
-                if (IN_MODE == IN_BNBWD) v2[it] = *reinterpret_cast<const uint4*>(in2 + off);
-            }
+            ok[it] = tl < ntiles && f >= 0 && f < F && t >= 0 && t < T;
+            const int64_t off = ((img + (int64_t)min(max(f, 0), F - 1) * T + min(max(t, 0), T - 1)) * kC + ch4 * 8);
+            v[it] = *reinterpret_cast<const uint4*>(in + off);
+            if (IN_MODE == IN_BNBWD) v2[it] = *reinterpret_cast<const uint4*>(in2 + off);
+            else v2[it] = make_uint4(0, 0, 0, 0);
         }
     };
     auto store_strip = [&]() {   // registers -> LDS with the producer's transform applied
@@ -209,8 +208,8 @@ __global__ __launch_bounds__(256, 2) void conv3x5_kernel(
         for (int it = 0; it < 4; ++it) {
             const int pos = it * 16 + (lane >> 2), t = t0 + pos;
             ev[it] = make_uint4(0, 0, 0, 0);
-            if (EPI != EPI_NONE && f < F && t < T)
-                ev[it] = *reinterpret_cast<const uint4*>(epi_src + (img + (int64_t)f * T + t) * kC + ch4 * 8);
+            if (EPI != EPI_NONE)    // clamped address: rows / positions past the edge are never stored
+                ev[it] = *reinterpret_cast<const uint4*>(epi_src + (img + (int64_t)min(f, F - 1) * T + min(t, T - 1)) * kC + ch4 * 8);
         }
         f32x16 acc[2];
 #pragma unroll

@@ -264,6 +264,51 @@ def cpu_baseline(args, V):
                       f"torch conv/BN/GEMM, python-loop SRU, torch CTC, torch Adam), {dt:.1f} s wall"}
 
 
+def comm_profile(dp, opt, step, args, world, ms_step_dp):
+    """The gradient exchange of the data-parallel step, measured after the timed region (all ranks take part):
+    every bucket's all-reduce alone (HIP events on the launch stream around a blocking collective, median of 5),
+    and the step without any exchange (each rank stepping on its own gradients).  exposed = step with the exchange
+    - step without; overlap_frac = the share of the stand-alone all-reduce time that backward hid."""
+    per_bucket = []
+    for lo, hi, _ in dp.buckets:
+        view = opt.flat_grad[lo:hi]
+        ts = []
+        for _r in range(5):
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            dist.all_reduce(view, group=dp.group)
+            e1.record()
+            torch.cuda.synchronize()
+            ts.append(e0.elapsed_time(e1))
+        ts.sort()
+        per_bucket.append(ts[len(ts) // 2])
+    # the step with the exchange switched off (replicas drift apart from here on: nothing is measured after this)
+    launch, finish = dp._launch, dp.finish
+    dp._launch = lambda b: None
+    try:
+        for i in range(2):
+            step(2 * 10 ** 6 + i)
+        dist.barrier()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for i in range(max(args.steps // 2, 2)):
+            step(2 * 10 ** 6 + 2 + i)
+        torch.cuda.synchronize()
+        ms_nocomm = 1000.0 * (time.perf_counter() - t0) / max(args.steps // 2, 2)
+    finally:
+        dp._launch, dp.finish = launch, finish
+    tm = torch.tensor([ms_nocomm], dtype=torch.float64, device=opt.flat_grad.device)
+    dist.all_reduce(tm, op=dist.ReduceOp.MAX)
+    ms_nocomm = float(tm.item())
+    total = sum(per_bucket)
+    exposed = max(ms_step_dp - ms_nocomm, 0.0)
+    return {"buckets_mb": [round((hi - lo) * 4 / 2 ** 20, 1) for lo, hi, _ in dp.buckets],
+            "allreduce_ms": [round(t, 3) for t in per_bucket], "allreduce_ms_total": total,
+            "ms_per_step_without_exchange": ms_nocomm, "exposed_ms": exposed,
+            "overlap_frac": (1.0 - exposed / total) if total > 0 else None,
+            "backend": dist.get_backend(dp.group)}
+
+
 def spawn_ranks(n):
     """`python bench.py --gpus N` typed as is: start N fresh rank processes of this script (one per GPU, the
     launcher's environment contract: RANK / LOCAL_RANK / WORLD_SIZE / MASTER_ADDR / MASTER_PORT) and relay rank 0's
@@ -294,11 +339,19 @@ def main():
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
     if world == 1 and "RANK" not in os.environ and (args.gpus > 1 or os.environ.get("BENCH_FORCE_SPAWN")):
         raise SystemExit(spawn_ranks(args.gpus))      # BENCH_FORCE_SPAWN: exercise the launcher on a 1-GPU box
+    # BENCH_SHARE_GPU / BENCH_BACKEND exist for the test that rehearses the N > 1 path on a one-GPU lease
+    # (two ranks on one card over gloo: RCCL refuses two ranks per device); the driver never sets them
+    if os.environ.get("BENCH_SHARE_GPU"):
+        local = 0
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=dev)
+        backend = os.environ.get("BENCH_BACKEND", "nccl")
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=dev)
+        else:
+            dist.init_process_group(backend)
 
     from speech_amd import data, net, ops
     from speech_amd.train import BucketedAllReduce, FlatAdam, lr_lambda_linear_warmup, train_step
@@ -340,6 +393,24 @@ def main():
     dt = float(tmax.item())
     loss_val = float(loss)
 
+    # N > 1: the same per-kernel timings and the gradient exchange's cost.  Every rank runs the same extra
+    # (untimed) steps and collectives in the same order; rank 0 reports.
+    ks_dp, comm = None, None
+    if world > 1:
+        ks_dp = {}
+        if args.dtype == "bf16":
+            ks_dp.update(gemm_in_step(step))
+            for which in ("sru_fwd", "sru_bwd"):
+                sb = sru_in_step(step, which)
+                if sb is not None:
+                    e = 2
+                    Tp_ = ((1 + N // 160) - 1) // 2 + 1
+                    by = Tp_ * B * 1024 * ((3 * e + 3 * e) if which == "sru_fwd" else (3 * e + e + e + e + 3 * e + e))
+                    ks_dp[which + "_kernel"] = {"bound": "hbm", "achieved": by / sb[0] / 1e6, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                                                "frac": by / sb[0] / 1e6 / HBM_PEAK_GBS, "ms": sb[0], "algorithmic_bytes": by,
+                                                "launches_per_step": sb[1] + 1, "timed": "in-step, one HIP event pair per launch"}
+        comm = comm_profile(dp, opt, step, args, world, 1000.0 * dt / args.steps)
+
     if rank == 0:
         value = B * args.seconds * world * args.steps / dt
         line = {
@@ -375,6 +446,14 @@ def main():
             line["kernels"] = ks
             if not args.no_cpu_baseline:
                 line["cpu_baseline"] = cpu_baseline(args, V)
+        else:
+            if ks_dp:
+                dom = max(ks_dp, key=lambda k: ks_dp[k]["ms"] * ks_dp[k]["launches_per_step"])
+                r = dict(ks_dp[dom])
+                r["kernel"], r["traffic"] = dom, None
+                line["roofline"] = {k: r[k] for k in ("bound", "achieved", "peak", "unit", "frac", "traffic", "kernel")}
+                line["kernels"] = ks_dp
+            line["comm"] = comm
         print(json.dumps(line), flush=True)
     if world > 1:
         dist.destroy_process_group()

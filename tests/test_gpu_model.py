@@ -559,6 +559,32 @@ def test_bench_self_launch_path(cuda):
     assert d["roofline"]["bound"] in ("hbm", "mfma") and 0 < d["roofline"]["frac"] < 1
 
 
+def test_bench_two_ranks_report_roofline_and_exchange(cuda):
+    """The N > 1 line of bench.py, rehearsed on the one-GPU lease: two ranks share the card over gloo
+    (BENCH_SHARE_GPU / BENCH_BACKEND; RCCL refuses two ranks per device).  Rank 0's single JSON line carries the
+    whole-job rate, a roofline object, and the gradient exchange's per-bucket times and overlap fraction."""
+    import json
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE")}
+    env.update(BENCH_SHARE_GPU="1", BENCH_BACKEND="gloo")
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1",
+                        "--batch", "4", "--seconds", "4"], env=env, capture_output=True, text=True, timeout=170)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["config"]["global_batch"] == 8 and d["scaling"] == "weak" and d["value"] > 0
+    assert d["config"]["parallelism"] == "dp2" and "cpu_baseline" not in d and d["roofline"]["frac"] > 0
+    c = d["comm"]
+    assert len(c["buckets_mb"]) == len(c["allreduce_ms"]) >= 2 and all(t > 0 for t in c["allreduce_ms"])
+    assert abs(sum(c["buckets_mb"]) - 4 * 33.5) < 4 * 3         # the whole f32 gradient arena
+    assert c["overlap_frac"] is not None and c["overlap_frac"] <= 1.0 and c["backend"] == "gloo"
+    assert c["ms_per_step_without_exchange"] > 0
+
+
 def test_model_forward_fp16(cuda):
     """compute_dtype = float16 (the reference evaluates with model.half(), scripts/eval_dataset.py): LayerNorm, the
     projections, the recurrence and the classifier run on their f16 instantiations; logits against the CPU

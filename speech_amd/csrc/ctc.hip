@@ -138,6 +138,7 @@ __global__ __launch_bounds__(256) void ctc_rows_vec_kernel(
     int label_stride, const int32_t* __restrict__ in_len, const int32_t* __restrict__ lab_len,
     int T, int B, int V, int blank, int Lmax, int RW, int modeB, float* __restrict__ lse2,
     float* __restrict__ rows) {
+    __shared__ __attribute__((aligned(16))) float srow[4][NV * 256];   // one row per wave (launched with 256 threads)
     const int lane = threadIdx.x & 63;
     const int wpb = blockDim.x >> 6;
     const int V4 = V >> 2;
@@ -179,13 +180,20 @@ __global__ __launch_bounds__(256) void ctc_rows_vec_kernel(
                                           fmaf(v[i].z, kLog2e, -l2), fmaf(v[i].w, kLog2e, -l2));
             }
         } else {
+            // gather the label positions from the row the wave already holds: registers -> the wave's LDS row ->
+            // indexed reads (re-reading z[idx] from memory fetched 1.4x the logits: PMC, round 1)
+            float4* s4 = reinterpret_cast<float4*>(srow[threadIdx.x >> 6]);
+#pragma unroll
+            for (int i = 0; i < NV; ++i) s4[lane + 64 * i] = v[i];
+            __builtin_amdgcn_wave_barrier();
             const int L = min(max(lab_len[b], 0), Lmax);
             for (int i = lane; i <= L; i += 64) {
                 int idx = blank;
                 if (i > 0) idx = (int)labels[(int64_t)b * label_stride + i - 1];
                 idx = min(max(idx, 0), V - 1);
-                out[i] = fmaf(z[idx], kLog2e, -l2);   // L1/L2 hit: the row was just read
+                out[i] = fmaf(srow[threadIdx.x >> 6][idx], kLog2e, -l2);
             }
+            __builtin_amdgcn_wave_barrier();
         }
     }
 }

@@ -134,7 +134,6 @@ def kernel_rooflines(args, model, wav, offs, labels, lens, Lmax, V, iters):
     ms = time_kernel(lambda: check(L.sp_melspec_fwd(ptr(wav), ptr(offs), B, T, ptr(plan.buf), ptr(masks), 0,
                                                     ptr(spec_buf), st), "mel"), iters)
     line("melspec_kernel", 4.0 * B * N + 4.0 * 80 * B * T, ms, 1)
-    # CTC: scores read + grad write + f64 alpha/beta lattice write and read (2*8*sum T'*S_b)
     Tp = (T - 1) // 2 + 1
     logits = torch.randn(B, Tp, V, device=dev) * 3
     il = torch.full((B,), Tp, dtype=torch.int32, device=dev)
@@ -144,7 +143,10 @@ def kernel_rooflines(args, model, wav, offs, labels, lens, Lmax, V, iters):
                                                     labels.stride(0), ptr(il), ptr(lens), Tp, B, V, 0, Lmax, 1.0,
                                                     ptr(nll), ptr(loss), ptr(grad), 0, ptr(ws), ws.numel(), st), "ctc"), iters)
     S = (2 * lens.float() + 1).sum().item()
-    line("ctc_fwd_bwd(3 kernels)", 2 * 4.0 * Tp * B * V + 2 * 8.0 * Tp * S, ms, 1)
+    # SURVEY 8(d)'s algorithmic figure: scores read + gradient written + an f32 alpha lattice written and read
+    # (the kernels spill f64 alpha AND beta -- 4x that term -- for the precision DESIGN.md section 4 explains;
+    # the roofline fraction is quoted against the algorithmic bytes, so that choice costs fraction, as it should)
+    line("ctc_fwd_bwd(3 kernels)", 2 * 4.0 * Tp * B * V + 2 * 4.0 * Tp * S, ms, 1)
     # decode: scores read + ids write
     ids = torch.empty((B, Tp), dtype=torch.int32, device=dev); nids = torch.empty(B, dtype=torch.int32, device=dev)
     ms = time_kernel(lambda: check(L.sp_greedy_decode(ptr(logits), _lib.dtype_code(logits), B, Tp, V, 0, None, ptr(ids),

@@ -159,6 +159,28 @@ def test_mel_full_size_properties(cuda):
     assert float((a[3, 0].cpu() - ref).abs().max()) <= 1e-4 * float(ref.abs().max())
 
 
+def test_mel_full_length_against_f64_dft(cuda):
+    """The sharp bound at production length: two 15 s utterances (noise + tone, a quiet one) against the float64
+    DFT restatement -- 2e-6 of the utterance peak on every bin, and element-relative 2e-4 on every bin that holds
+    at least 1e-3 of the peak (f32 FFT round-off is relative to the frame's energy, not to the bin)."""
+    from speech_amd import ops
+    g = torch.Generator().manual_seed(21)
+    N = 240000
+    t = torch.arange(N, dtype=torch.float32) / 16000.0
+    wavs = [(0.1 * torch.randn(N, generator=g) + 0.3 * torch.sin(2 * torch.pi * 440.0 * t)).clamp(-1, 1),
+            1e-3 * torch.randn(N - 777, generator=g)]
+    flat = torch.cat(wavs)
+    offs = torch.tensor([0, N, 2 * N - 777], dtype=torch.int64)
+    out = ops.melspec(flat.to(cuda), offs.to(cuda)).cpu().numpy()
+    for b, w in enumerate(wavs):
+        ref = np.asarray(omel.mel_spectrogram_f64(w.numpy()))
+        got = out[b, 0, :, : ref.shape[-1]].astype(np.float64)
+        peak = np.abs(ref).max()
+        assert np.abs(got - ref).max() <= 2e-6 * peak, b
+        big = np.abs(ref) >= 1e-3 * peak
+        assert (np.abs(got - ref)[big] / np.abs(ref)[big]).max() <= 2e-4, b
+
+
 # =============================================================================== ctc
 def _ctc_hip(cuda, logits_tbv, labels, il, ll, time_major=True, max_label_len=None):
     from speech_amd import ops

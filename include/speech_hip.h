@@ -203,12 +203,23 @@ int sp_sru_bwd(const void* U, const void* xres, const float* wc, const float* bi
  * 1: clip_grad_norm_ applied to g / grad_div, the gradient the update uses (data parallel: g is the sum
  * over the ranks, grad_div the world size), no host sync.  decoupled != 0: p *= 1 - lr*wd after the update
  * (bitsandbytes kernels); 0: g += wd * p (L2).
+ * sp_adam8_step_f32: the same update with the moments held as bitsandbytes-style block-wise 8-bit codes
+ * (train.py:254 Adam8bit): state1 / state2 uint8 [n], absmax1 / absmax2 f32 [ceil(n / SP_ADAM8_BLOCK)]; a
+ * moment = code_table[state] * absmax of its block; signed dynamic-exponent table for the first moment,
+ * unsigned for the second; after the update every block is re-scaled to its new absolute maximum and
+ * re-coded to the nearest table entry.  Fresh state: state1 = 127 (the code of zero), state2 = 0, absmax = 0.
+ * n % 4 == 0.  Parity unpinned (bitsandbytes absent; the table follows its published construction).
  * --------------------------------------------------------------------------------------- */
 #define SP_SUMSQ_WORDS 1025
+#define SP_ADAM8_BLOCK 2048
 int sp_sumsq_f32(const float* x, int64_t n, float* out, void* stream);
 int sp_adam_step_f32(float* p, const float* g, float* m, float* v, int64_t n, float lr, float beta1,
                      float beta2, float eps, float weight_decay, int step, int decoupled,
                      const float* sumsq, float max_norm, float grad_div, void* stream);
+int sp_adam8_step_f32(float* p, const float* g, uint8_t* state1, uint8_t* state2, float* absmax1,
+                      float* absmax2, int64_t n, float lr, float beta1, float beta2, float eps,
+                      float weight_decay, int step, int decoupled, const float* sumsq, float max_norm,
+                      float grad_div, void* stream);
 
 /* ---------------------------------------------------------------------------------------
  * Conv / BatchNorm / ReLU residual stack.  Replaces net.py:9-42, :56-59 (cuDNN Conv2d(1,32,3,s2),

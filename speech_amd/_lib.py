@@ -11,6 +11,7 @@ LIB_PATH = os.path.join(_HERE, "libspeech_hip.so")
 
 SP_F32, SP_F16, SP_BF16 = 0, 1, 2
 SUMSQ_WORDS = 1025   # SP_SUMSQ_WORDS of include/speech_hip.h
+ADAM8_BLOCK = 2048   # SP_ADAM8_BLOCK
 CONV_WGRAD_WS_WORDS = 512 * 15 * 32 * 32   # SP_CONV_WGRAD_WS_WORDS: one slab per persistent workgroup
 BN_SUMS_WORDS = 8 * 64 + 1024 * 64 + 64   # SP_BN_SUMS_WORDS: [8][64] rows, per-workgroup partials, their count
 
@@ -43,6 +44,7 @@ SIGNATURES = {
                         _vp]),
     "sp_sumsq_f32": (_i, [_vp, _i64, _vp, _vp]),
     "sp_adam_step_f32": (_i, [_vp, _vp, _vp, _vp, _i64, _f, _f, _f, _f, _f, _i, _i, _vp, _f, _f, _vp]),
+    "sp_adam8_step_f32": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _i64, _f, _f, _f, _f, _f, _i, _i, _vp, _f, _f, _vp]),
     "sp_conv_pack_w": (_i, [_vp, _i, _vp, _vp]),
     "sp_conv3x5": (_i, [_vp, _vp, _vp, _i, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp, _vp, _vp]),
     "sp_conv3x5_wgrad": (_i, [_vp, _vp, _i, _vp, _vp, _vp, _i, _i, _i, _vp, _vp, _vp]),

@@ -24,7 +24,7 @@ import torch
 import torch.distributed as dist
 
 from . import data, decoder, net, ops
-from ._lib import SUMSQ_WORDS, check, lib, ptr, stream_ptr
+from ._lib import ADAM8_BLOCK, SUMSQ_WORDS, check, lib, ptr, stream_ptr
 
 
 def lr_lambda_linear_warmup(current_step, num_warmup_steps, num_training_steps):
@@ -56,10 +56,13 @@ class IterMeter(object):
 class FlatAdam(torch.optim.Optimizer):
     """Adam over one flat fp32 arena.  Every parameter's .data and .grad become views into two
     contiguous buffers (16-byte aligned slices), so the global grad norm, the clip and the update
-    are two kernel launches, and gradient buckets for the all-reduce are plain slices."""
+    are two kernel launches, and gradient buckets for the all-reduce are plain slices.
+    state_bits = 8 keeps the moments as bitsandbytes-style block-wise 8-bit codes (train.py:254 Adam8bit;
+    blocks of 2048 elements of the flat arena, one absmax per block and moment): 2 bytes of state per
+    parameter instead of 8, and 16 instead of 28 bytes of traffic per parameter and step."""
 
     def __init__(self, params, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.0,
-                 decoupled_weight_decay=True):
+                 decoupled_weight_decay=True, state_bits=32):
         params = [p for p in params if p.requires_grad]
         super().__init__(params, dict(lr=lr, betas=betas, eps=eps, weight_decay=weight_decay))
         self.plist = params
@@ -71,8 +74,18 @@ class FlatAdam(torch.optim.Optimizer):
         self.total = total
         self.flat = torch.zeros(total, dtype=torch.float32, device=dev)
         self.flat_grad = torch.zeros(total, dtype=torch.float32, device=dev)
-        self.exp_avg = torch.zeros(total, dtype=torch.float32, device=dev)
-        self.exp_avg_sq = torch.zeros(total, dtype=torch.float32, device=dev)
+        if state_bits not in (8, 32):
+            raise ValueError("state_bits must be 32 or 8")
+        self.state_bits = state_bits
+        if state_bits == 32:
+            self.exp_avg = torch.zeros(total, dtype=torch.float32, device=dev)
+            self.exp_avg_sq = torch.zeros(total, dtype=torch.float32, device=dev)
+        else:
+            nblk = (total + ADAM8_BLOCK - 1) // ADAM8_BLOCK
+            self.exp_avg = torch.full((total,), 127, dtype=torch.uint8, device=dev)      # code 127 = 0 (signed table)
+            self.exp_avg_sq = torch.zeros(total, dtype=torch.uint8, device=dev)           # code 0 = 0 (unsigned table)
+            self.absmax1 = torch.zeros(nblk, dtype=torch.float32, device=dev)
+            self.absmax2 = torch.zeros(nblk, dtype=torch.float32, device=dev)
         self.sumsq = torch.zeros(SUMSQ_WORDS, dtype=torch.float32, device=dev)   # [0] = sum, rest partials
         for p, off in zip(params, self.offsets):
             n = p.numel()
@@ -98,6 +111,13 @@ class FlatAdam(torch.optim.Optimizer):
             if max_norm and max_norm > 0:
                 check(lib().sp_sumsq_f32(ptr(self.flat_grad), self.total, ptr(self.sumsq), s), "sp_sumsq_f32")
                 sumsq = self.sumsq
+            if self.state_bits == 8:
+                check(lib().sp_adam8_step_f32(ptr(self.flat), ptr(self.flat_grad), ptr(self.exp_avg), ptr(self.exp_avg_sq),
+                                              ptr(self.absmax1), ptr(self.absmax2), self.total, float(g["lr"]),
+                                              float(g["betas"][0]), float(g["betas"][1]), float(g["eps"]),
+                                              float(g["weight_decay"]), self.t, int(self.decoupled), ptr(sumsq),
+                                              float(max_norm or 0.0), float(grad_div), s), "sp_adam8_step_f32")
+                return
             check(lib().sp_adam_step_f32(ptr(self.flat), ptr(self.flat_grad), ptr(self.exp_avg),
                                          ptr(self.exp_avg_sq), self.total, float(g["lr"]),
                                          float(g["betas"][0]), float(g["betas"][1]), float(g["eps"]),
@@ -105,13 +125,22 @@ class FlatAdam(torch.optim.Optimizer):
                                          float(max_norm or 0.0), float(grad_div), s), "sp_adam_step_f32")
 
     def state_dict(self):
-        return {"t": self.t, "exp_avg": self.exp_avg.clone(), "exp_avg_sq": self.exp_avg_sq.clone(),
-                "param_groups": [{k: v for k, v in self.param_groups[0].items() if k != "params"}]}
+        sd = {"t": self.t, "exp_avg": self.exp_avg.clone(), "exp_avg_sq": self.exp_avg_sq.clone(),
+              "state_bits": self.state_bits,
+              "param_groups": [{k: v for k, v in self.param_groups[0].items() if k != "params"}]}
+        if self.state_bits == 8:
+            sd["absmax1"], sd["absmax2"] = self.absmax1.clone(), self.absmax2.clone()
+        return sd
 
     def load_state_dict(self, sd):
+        if sd.get("state_bits", 32) != self.state_bits:
+            raise ValueError(f"checkpoint holds {sd.get('state_bits', 32)}-bit optimizer state, this optimizer {self.state_bits}-bit")
         self.t = sd["t"]
         self.exp_avg.copy_(sd["exp_avg"])
         self.exp_avg_sq.copy_(sd["exp_avg_sq"])
+        if self.state_bits == 8:
+            self.absmax1.copy_(sd["absmax1"])
+            self.absmax2.copy_(sd["absmax2"])
 
 
 class BucketedAllReduce:
@@ -399,7 +428,8 @@ def main(hparams):
     if hparams.get("resume"):
         model.load_checkpoint(torch.load(hparams["resume"], map_location="cuda", weights_only=True))
     log("Num Model Parameters", sum(p.nelement() for p in model.parameters()))
-    optimizer = FlatAdam(model.parameters(), lr=hparams["learning_rate"], weight_decay=hparams["weight_decay"])
+    optimizer = FlatAdam(model.parameters(), lr=hparams["learning_rate"], weight_decay=hparams["weight_decay"],
+                         state_bits=hparams.get("optim_bits", 32))
     dp = BucketedAllReduce(optimizer) if world > 1 else None
 
     train_loader, sampler, evals = build_loaders(hparams, rank, world)
@@ -450,6 +480,8 @@ def parse_args(argv=None):
     p.add_argument("--manifest_root", type=str, default="", help="directory the datasets/... manifest paths are relative to")
     p.add_argument("--ibm_root", type=str, default="/hd1/ibm")
     p.add_argument("--num_workers", type=int, default=6)
+    p.add_argument("--optim_bits", type=int, choices=[32, 8], default=32,
+                   help="optimizer state: 32 = fp32 moments, 8 = block-wise 8-bit moments as bitsandbytes Adam8bit (train.py:254)")
     a = p.parse_args(argv)
     return {
         "datasets": a.datasets, "multiplier": a.multiplier, "batch_size": 32 * a.multiplier,
@@ -458,7 +490,7 @@ def parse_args(argv=None):
         "clip_grad_norm": a.clip_grad_norm, "one_iter": a.one_iter, "projection_size": a.projection_size,
         "synthetic": a.synthetic, "synthetic_clips": a.synthetic_clips, "steps": a.steps,
         "dtype": a.dtype, "checkpoint": a.checkpoint, "resume": a.resume, "eval_dtype": a.eval_dtype,
-        "device": a.device, "manifest_root": a.manifest_root, "ibm_root": a.ibm_root, "num_workers": a.num_workers,
+        "optim_bits": a.optim_bits, "device": a.device, "manifest_root": a.manifest_root, "ibm_root": a.ibm_root, "num_workers": a.num_workers,
         "root_map": tuple(tuple(kv.split("=", 1)) for kv in a.root_map.split(",") if kv) or None,
     }
 

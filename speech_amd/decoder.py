@@ -163,7 +163,8 @@ class BeamSearchDecoderCTC:
 
     def decode(self, logits, beam_width=DEFAULT_BEAM_WIDTH, beam_prune_logp=DEFAULT_PRUNE_LOGP,
                token_min_logp=DEFAULT_MIN_TOKEN_LOGP):
-        return self._search(logits, beam_width, beam_prune_logp, token_min_logp, 1)[0][0][0]
+        beams = self._search(logits, beam_width, beam_prune_logp, token_min_logp, 1)[0]
+        return beams[0][0] if beams else ""         # no hypothesis survives only when the scores are not finite
 
     def decode_batch(self, pool, logits_list, beam_width=DEFAULT_BEAM_WIDTH, beam_prune_logp=DEFAULT_PRUNE_LOGP,
                      token_min_logp=DEFAULT_MIN_TOKEN_LOGP, frame_lengths=None):
@@ -172,7 +173,7 @@ class BeamSearchDecoderCTC:
         pool has workers when one is given, 16 otherwise (eval_dataset.py:47 uses Pool(16))."""
         n_threads = getattr(pool, "_processes", None) or 16
         res = self._search(logits_list, beam_width, beam_prune_logp, token_min_logp, 1, frame_lengths, n_threads)
-        return [beams[0][0] for beams in res]
+        return [beams[0][0] if beams else "" for beams in res]
 
 
 def build_ctcdecoder(labels, kenlm_model_path=None, unigrams=None, alpha=DEFAULT_ALPHA, beta=DEFAULT_BETA,

@@ -228,7 +228,8 @@ int sp_adam8_step_f32(float* p, const float* g, uint8_t* state1, uint8_t* state2
  *
  * sp_conv_pack_w: f32 weight [32][32][3][5] -> bf16 MFMA fragment image (15*2*64*8 elements);
  *   bwd_data 1 packs the flipped, channel-transposed weight of the data gradient, 2 both images
- *   (forward at wpack[0], backward-data at wpack[15*2*64*8]) in one launch.
+ *   (forward at wpack[0], backward-data at wpack[15*2*64*8]) in one launch.  sp_conv_pack_w_batched: the same for
+ *   L <= 16 weights in ONE launch (w / wpack are HOST arrays of L device pointers).
  * sp_conv3x5: out = conv(tf(in)) (+ bias).  in_mode 0: tf = id; 1: tf = relu(c[0:32]*in + c[32:64])
  *   (BatchNorm+ReLU of the producer, applied while staging); 2: tf = c[0:32]*in + c[32:64]*in2 +
  *   c[64:96] (BatchNorm backward from (dz, y)).  Zero padding applies after tf.  epi_mode 0: none
@@ -262,6 +263,7 @@ int sp_adam8_step_f32(float* p, const float* g, uint8_t* state1, uint8_t* state2
 #define SP_CONV_WGRAD_SLABS 512
 #define SP_CONV_WGRAD_WS_WORDS (SP_CONV_WGRAD_SLABS * 15 * 32 * 32)
 int sp_conv_pack_w(const float* w, int bwd_data, void* wpack, void* stream);
+int sp_conv_pack_w_batched(const float* const* w, int L, int bwd_data, void* const* wpack, void* stream);
 int sp_conv3x5(const void* in, const void* in2, const float* coef, int in_mode, const void* wpack,
                const float* bias, const void* epi_src, const float* epi_coef, int epi_mode, int B,
                int F, int T, void* out, float* bn_sums, void* stream);

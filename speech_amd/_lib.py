@@ -46,6 +46,7 @@ SIGNATURES = {
     "sp_adam_step_f32": (_i, [_vp, _vp, _vp, _vp, _i64, _f, _f, _f, _f, _f, _i, _i, _vp, _f, _f, _vp]),
     "sp_adam8_step_f32": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _i64, _f, _f, _f, _f, _f, _i, _i, _vp, _f, _f, _vp]),
     "sp_conv_pack_w": (_i, [_vp, _i, _vp, _vp]),
+    "sp_conv_pack_w_batched": (_i, [_vp, _i, _i, _vp, _vp]),
     "sp_conv3x5": (_i, [_vp, _vp, _vp, _i, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp, _vp, _vp]),
     "sp_conv3x5_wgrad": (_i, [_vp, _vp, _i, _vp, _vp, _vp, _i, _i, _i, _vp, _vp, _vp]),
     "sp_conv_stem_fwd": (_i, [_vp, _vp, _vp, _i, _i, _i, _vp, _vp]),

@@ -35,6 +35,20 @@ def _pack_both(w):
     return out[:PACK_ELEMS], out[PACK_ELEMS:]
 
 
+def _pack_many(ws, bwd_data):
+    """Every weight of `ws` packed in one launch -> list of (forward image, backward-data image or None)."""
+    import ctypes
+    n = len(ws)
+    per = (2 if bwd_data == 2 else 1) * PACK_ELEMS
+    out = torch.empty((n, per), dtype=torch.bfloat16, device=ws[0].device)
+    arr = ctypes.c_void_p * n
+    check(lib().sp_conv_pack_w_batched(arr(*[w.data_ptr() for w in ws]), n, int(bwd_data),
+                                       arr(*[out[i].data_ptr() for i in range(n)]), stream_ptr()), "sp_conv_pack_w_batched")
+    if bwd_data == 2:
+        return [(out[i, :PACK_ELEMS], out[i, PACK_ELEMS:]) for i in range(n)]
+    return [(out[i], None) for i in range(n)]
+
+
 _wgrad_ws = {}
 
 
@@ -84,13 +98,15 @@ class _ConvStackFn(torch.autograd.Function):
             x = torch.empty((B, F, T, C), dtype=torch.bfloat16, device=dev)
             check(lib().sp_conv_stem_fwd(ptr(spec), ptr(sw), ptr(sb), B, Fin, Tin, ptr(x), s), "sp_conv_stem_fwd")
             saved = []
+            # all convolution weights packed in one launch (forward and, in training, backward-data images)
+            cws = [_f32(params[8 * i + j]) for i in range(nblk) for j in (0, 4)]
+            packs = _pack_many(cws, 2 if training else 0)
             for i in range(nblk):
                 c1w, c1b, b1w, b1b, c2w, c2b, b2w, b2b = [_f32(p) for p in params[8 * i: 8 * i + 8]]
                 rm1, rv1, rm2, rv2 = bufs[4 * i: 4 * i + 4]
                 s1 = torch.empty(BN_SUMS_WORDS, dtype=torch.float32, device=dev) if training else None
                 s2 = torch.empty(BN_SUMS_WORDS, dtype=torch.float32, device=dev) if training else None
-                p1f, p1b = _pack_both(c1w) if training else (_pack(c1w, 0), None)
-                p2f, p2b = _pack_both(c2w) if training else (_pack(c2w, 0), None)
+                (p1f, p1b), (p2f, p2b) = packs[2 * i], packs[2 * i + 1]
                 y1 = _conv(x, None, None, IN_ID, p1f, c1b, None, None, EPI_NONE, B, F, T, s1)
                 coef1, save1 = _bn_fwd(s1, npos, b1w, b1b, rm1, rv1, momentum, eps, training)
                 y2 = _conv(y1, None, coef1, IN_BNRELU, p2f, c2b, None, None, EPI_NONE, B, F, T, s2)
@@ -184,9 +200,8 @@ def conv_stack(spec, cnn, blocks, training):
         params += [blk.conv1.weight, blk.conv1.bias, blk.bn1.weight, blk.bn1.bias,
                    blk.conv2.weight, blk.conv2.bias, blk.bn2.weight, blk.bn2.bias]
         bufs += [blk.bn1.running_mean, blk.bn1.running_var, blk.bn2.running_mean, blk.bn2.running_var]
-        if training:
-            blk.bn1.num_batches_tracked += 1
-            blk.bn2.num_batches_tracked += 1
+    if training:      # one launch for all counters instead of one each
+        torch._foreach_add_([b.num_batches_tracked for blk in blocks for b in (blk.bn1, blk.bn2)], 1)
     bn = blocks[0].bn1
     return _ConvStackFn.apply(spec, bool(training), float(bn.momentum), float(bn.eps), cnn.weight, cnn.bias,
                               *params, *bufs)

@@ -66,7 +66,13 @@ enum { EPI_NONE = 0, EPI_MASK = 1, EPI_ADD = 2 };
 // weight pack: wpack[(tap*2+half)*64 + lane][8], lane (r = lane&31, h = lane>>5), element j =
 // Weff[out = r][in = 16 half + 8 h + j][tap].  bwd_data: Weff[ci][co][kh][kw] = w[co][ci][2-kh][4-kw].
 // ---------------------------------------------------------------------------------------------
-__global__ void conv_pack_kernel(const float* __restrict__ w, int bwd_data, __hip_bfloat16* __restrict__ wpack) {
+constexpr int kConvPackBatch = 16;
+struct ConvPackBatch { const float* w[kConvPackBatch]; __hip_bfloat16* wpack[kConvPackBatch]; };
+
+// blockIdx.y = weight of the batch: every convolution of the stack packed in one launch
+__global__ void conv_pack_kernel(ConvPackBatch pb, int bwd_data) {
+    const float* __restrict__ w = pb.w[blockIdx.y];
+    __hip_bfloat16* __restrict__ wpack = pb.wpack[blockIdx.y];
     int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (bwd_data == 2) {   // both layouts in one launch: forward in wpack[0:N], backward-data in wpack[N:2N]
         if (i >= 2 * 15 * 2 * 64 * 8) return;
@@ -996,12 +1002,22 @@ static int check_act(const char* who, int B, int F, int T) {
 using namespace sp;
 typedef __hip_bfloat16 bf16;
 
-extern "C" int sp_conv_pack_w(const float* w, int bwd_data, void* wpack, void* stream) {
-    SP_CHECK_ARG(w && wpack, "sp_conv_pack_w: null pointer");
+extern "C" int sp_conv_pack_w_batched(const float* const* w, int L, int bwd_data, void* const* wpack, void* stream) {
+    SP_CHECK_ARG(w && wpack && L >= 1 && L <= kConvPackBatch, "sp_conv_pack_w: null pointer or L=%d outside [1,%d]", L, kConvPackBatch);
     SP_CHECK_ARG(bwd_data >= 0 && bwd_data <= 2, "sp_conv_pack_w: bwd_data %d (0 forward, 1 backward-data, 2 both)", bwd_data);
-    hipLaunchKernelGGL(conv_pack_kernel, dim3(bwd_data == 2 ? 120 : 60), dim3(256), 0, (hipStream_t)stream, w, bwd_data,
-                       (bf16*)wpack);
+    ConvPackBatch pb;
+    for (int l = 0; l < kConvPackBatch; ++l) {
+        const int q = l < L ? l : 0;
+        pb.w[l] = w[q];
+        pb.wpack[l] = (bf16*)wpack[q];
+        SP_CHECK_ARG(pb.w[l] && pb.wpack[l], "sp_conv_pack_w: null pointer (weight %d)", q);
+    }
+    hipLaunchKernelGGL(conv_pack_kernel, dim3(bwd_data == 2 ? 120 : 60, L), dim3(256), 0, (hipStream_t)stream, pb, bwd_data);
     return check_launch("conv_pack_kernel");
+}
+
+extern "C" int sp_conv_pack_w(const float* w, int bwd_data, void* wpack, void* stream) {
+    return sp_conv_pack_w_batched(&w, 1, bwd_data, &wpack, stream);
 }
 
 extern "C" int sp_conv3x5(const void* in, const void* in2, const float* coef, int in_mode, const void* wpack,

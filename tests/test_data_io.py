@@ -190,3 +190,27 @@ def test_load_checkpoint_key_tolerance():
     del stripped["sru_layers.rnn_lst.0.bias"]
     with pytest.raises(RuntimeError, match="rnn_lst.0.bias"):
         dst.load_checkpoint(stripped)
+
+
+def test_sentence_piece_script(tmp_path):
+    """scripts/sentence_piece.py mirror: transcripts gathered from a pickled manifest (path rewriting included), a
+    small BPE model trained, and text.SentencePieceVocab reading it back."""
+    import pickle
+    spm = pytest.importorskip("sentencepiece")  # noqa: F841
+    from speech_amd import text
+    from speech_amd.scripts import sentence_piece as sps
+    real = tmp_path / "hd1"
+    real.mkdir()
+    words = "the quick brown fox jumps over the lazy dog and runs far away from here".split()
+    entries = []
+    for i in range(40):
+        (real / f"c{i}.txt").write_text(" ".join(words[(i + j) % len(words)] for j in range(6)) + "\n")
+        entries.append((str(tmp_path / "data" / f"c{i}.wav"), 16000))
+    (tmp_path / "m.pkl").write_bytes(pickle.dumps(entries))
+    out = tmp_path / "sp" / "sentences.txt"
+    n = sps.gather_sentences([str(tmp_path / "m.pkl")], str(out), ((str(tmp_path / "data"), str(real)),))
+    assert n == 40 and len(out.read_text().splitlines()) == 40
+    model = sps.generate_sp_model(str(out), vocab_size=40, model_type="bpe", model_prefix=str(tmp_path / "sp" / "tv"))
+    vocab = text.SentencePieceVocab(model)
+    ids = vocab.text_to_int("the lazy dog")
+    assert min(ids) >= 1 and vocab.size == 41 and vocab.int_to_text(ids) == "the lazy dog"

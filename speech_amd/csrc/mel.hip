@@ -23,124 +23,129 @@ namespace sp {
 using namespace melmath;
 
 constexpr int kNfft = 400, kHop = 160, kBins = 201, kMels = 80;
-constexpr int kF = 8;           // frames per wave
-constexpr int kWPB = 4;         // waves per block
-constexpr int kMagStride = 201; // odd stride: conflict-free column reads
+constexpr int kF = 8;             // frames per wave
+constexpr int kWPB = 4;           // waves per block
+constexpr int kZStride = 200;     // complex points per frame (1600 B: the 25-point transforms' reads are conflict-free)
+constexpr int kMagStride = 201;   // odd stride: conflict-free column reads
 constexpr int kTiles = kMels / 16;
-constexpr int kMaxBlk = kTiles * 51;
+constexpr int kGroup = 2;         // 4-bin blocks per trip of the projection loop
+constexpr int kMaxBlk = kTiles * 52 + 2 * kGroup;
+constexpr int kStage = (kF - 1) * kHop + kNfft;   // samples a wave's 8 frames touch: 1520
 
 struct MelPlan {
     float win[kNfft];
     cf tw200[25][8];   // W200^(n2*k1)
     cf tw400[104];     // W400^k, k = 0..100
-    int tile_blk0[8];  // first block of tile in fbt
-    int tile_nblk[8];
-    int tile_k0[8];    // first bin of tile
-    float fbt[kMaxBlk][64];  // A operand images: lane l -> fb[k0 + 4 blk + (l>>4)][16 tile + (l&15)]
+    // The five 16-mel tiles are dealt to the two waves of a pair (each wave projects its tiles for the pair's 16
+    // frames): slots [0, split) belong to the even wave, [split, kTiles) to the odd one, balanced by block count.
+    int slot_tile[8];  // tile id of the slot
+    int slot_nblk[8];  // 4-bin blocks of the tile, a multiple of kGroup (zero rows pad it)
+    int slot_k0[8];    // first bin of the tile's first block
+    int slot_blk0[8];  // first image of the slot in fbt
+    int split;
+    int pad_[3];
+    // A operand images in slot order, kGroup all-zero blocks after each wave's share (the loop requests one
+    // group ahead): lane l -> fb[k0 + 4 blk + (l>>4)][16 tile + (l&15)]
+    float fbt[kMaxBlk][64];
 };
 
-// Per-wave LDS: the 200-point complex intermediate of 8 frames; after phase 3 has pulled it into
-// registers the same bytes hold the 8 x 201 magnitudes (12.8 KB per wave, 51 KB per block, three
-// blocks per CU).
-struct WaveLds {
-    union {
-        cf yz[kF][200];
-        float mag[kF][kMagStride];
-    };
-};
-
+using f32x2 = __attribute__((ext_vector_type(2))) float;
 using f32x4 = __attribute__((ext_vector_type(4))) float;
+// Every LDS access of the kernel goes through these types: the three views of a wave's buffer (staged samples,
+// complex intermediates, magnitudes) overlap on purpose, so the compiler must keep their program order.
+typedef float __attribute__((may_alias)) lds_f1;
+typedef f32x2 __attribute__((may_alias)) lds_f2;
+typedef f32x4 __attribute__((may_alias)) lds_f4;
+typedef f32x4 __attribute__((may_alias, aligned(4))) gmem_f4;   // 16-byte load of 4-byte aligned samples
 
-// The kernel is latency-bound, not issue-bound (one wave runs ~2.7 k instructions on 8 frames, the
-// chip holds 3 waves per SIMD): every phase therefore issues all of its loads before its first use
-// (straight-line code, registers instead of occupancy), and the mel projection runs its A-operand
-// loads eight MFMAs ahead in a register ring.
+// Per-wave LDS, 12 800 (+ 64 of padding) bytes, three views one after the other in time:
+//   smp  the 1520 samples the 8 frames touch (bytes 0..6080), read by phase 1 frame pair by frame pair from the
+//        LAST pair to the first, so that the pair's 8-point transforms can go to
+//   yz   [frame][200] complex (1600 bytes per frame) without touching samples a later pass still needs;
+//        phase 2 transforms it in place;
+//   mag  [frame][201] magnitudes (804 bytes per frame): frame f's magnitudes land on yz of frames <= f / 2,
+//        which phase 3 has consumed by then (frame 0: all four reads are issued before the first write, and
+//        one wave's LDS operations execute in order).
+constexpr int kWaveLdsBytes = kF * kZStride * 8 + 64;   // + 16 banks: the pair's two magnitude images do not collide
+static_assert(2 * kZStride * 8 >= (kHop + kNfft) * 4, "pass 1 writes above the samples pass 0 still needs");
+static_assert(kWaveLdsBytes % 16 == 0, "16-byte staging stores");
+
+__device__ __forceinline__ cf ld2(const char* p) {
+    const f32x2 v = *reinterpret_cast<const lds_f2*>(p);
+    return mk(v.x, v.y);
+}
+__device__ __forceinline__ void st2(char* p, cf v) {
+    f32x2 t;
+    t.x = v.re;
+    t.y = v.im;
+    *reinterpret_cast<lds_f2*>(p) = t;
+}
+__device__ __forceinline__ void st1(char* p, float v) { *reinterpret_cast<lds_f1*>(p) = v; }
+
 // S = sample type: float in [-1, 1], or int16_t PCM read as sample / 32768 (exact in f32: what
 // torchaudio.load(normalize=True) hands the reference for 16-bit files) -- half the bytes to read.
 __device__ __forceinline__ float pcm(const float* x, int i) { return x[i]; }
 __device__ __forceinline__ float pcm(const int16_t* x, int i) { return (float)x[i] * (1.f / 32768.f); }
 
+// Staging and phases 1-3 for one wave: samples of 8 frames -> their 201 magnitudes each, in the wave's LDS.
 template <typename S>
-__global__ __launch_bounds__(64 * kWPB, 3) void melspec_kernel(
-    const S* __restrict__ wav, const int64_t* __restrict__ offs, int T_max,
-    const MelPlan* __restrict__ plan, const int32_t* __restrict__ masks, int flags,
-    float* __restrict__ out) {
-    __shared__ WaveLds s_lds[kWPB];
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    WaveLds& L = s_lds[wave];
-    const int b = blockIdx.y;
-    const int t0 = (blockIdx.x * kWPB + wave) * kF;
-    if (t0 >= T_max) return;
-    const int64_t off = offs[b];
-    const int N = (int)(offs[b + 1] - off);
-    const int Tb = N > 0 ? 1 + N / kHop : 0;
-    const S* x = wav + off;
-    float* outb = out + (int64_t)b * kMels * T_max;
-
-    if (t0 >= Tb) {  // pure padding: zeros
-        for (int i = lane; i < kMels * kF; i += 64) {
-            const int m = i >> 3, f = i & 7;
-            if (t0 + f < T_max) outb[(int64_t)m * T_max + t0 + f] = 0.f;
+__device__ __forceinline__ void transform_frames(const S* __restrict__ x, int N, int t0, const MelPlan* __restrict__ plan,
+                                                 char* L, int lane) {
+    // ------------------------------------------------------------------ staging
+    // The wave's 1520 samples, [t0*160 - 200, (t0+7)*160 + 200), are read ONCE, coalesced, into LDS; the
+    // 2.5-fold frame overlap and the stride-50 gathers of the 8-point transforms are served from there.
+    // Waves at an utterance's ends (reflection, frames past the end) take the element-wise path.
+    const int s0 = t0 * kHop - kNfft / 2;
+    const bool interior = s0 >= 0 && s0 + kStage <= N;
+    if (sizeof(S) == 4 && interior) {
+        const gmem_f4* src = reinterpret_cast<const gmem_f4*>(x + s0);
+        f32x4 v[6];
+#pragma unroll
+        for (int i = 0; i < 6; ++i) v[i] = src[min(lane + 64 * i, kStage / 4 - 1)];
+#pragma unroll
+        for (int i = 0; i < 6; ++i)
+            if (lane + 64 * i < kStage / 4) reinterpret_cast<lds_f4*>(L)[lane + 64 * i] = v[i];
+    } else {
+#pragma unroll 4
+        for (int i = 0; i < (kStage + 63) / 64; ++i) {
+            const int j = lane + 64 * i;
+            int idx = interior ? s0 + j : reflect(s0 + j, N);
+            idx = min(max(idx, 0), N - 1);
+            const float v = pcm(x, idx);
+            if (j < kStage) st1(L + 4 * j, v);
         }
-        return;
     }
 
     // ------------------------------------------------------------------ phase 1
-    // 200 lane-tasks (frame, n2): lane = (frame parity, n2) and 4 passes walk the frame pairs, so a
-    // lane's 16 window taps and 7 twiddles are loaded once; the 16 samples of ALL passes are
-    // requested before the first butterfly (interior waves: plain indices, no reflection).
-    int mf0 = 0, mfw = 0, mt0 = 0, mtw = 0;
-    if (masks) {
-        mf0 = masks[b * 4 + 0]; mfw = masks[b * 4 + 1];
-        mt0 = masks[b * 4 + 2]; mtw = masks[b * 4 + 3];
-    }
-    const bool interior = (t0 * kHop - kNfft / 2 >= 0) && ((t0 + kF - 1) * kHop + kNfft / 2 <= N) &&
-                          (t0 + kF <= Tb);
+    // 200 lane-tasks (frame, n2): lane = (frame parity, n2) and 4 passes walk the frame pairs from the last to
+    // the first (see the LDS note above); a lane's 16 window taps and 7 twiddles are loaded once.
     {
         const int fh = lane >= 25 ? 1 : 0;
         const int n2 = min(lane - 25 * fh, 24);
         const bool active = lane < 50;
-        float xs[4][16];
-#pragma unroll
-        for (int p = 0; p < 4; ++p) {
-            const int t = t0 + 2 * p + fh;
-            const int base = t * kHop - kNfft / 2 + 2 * n2;
-            if (interior) {
-#pragma unroll
-                for (int n1 = 0; n1 < 8; ++n1) {
-                    xs[p][2 * n1] = pcm(x, base + 50 * n1);
-                    xs[p][2 * n1 + 1] = pcm(x, base + 50 * n1 + 1);
-                }
-            } else {
-                const bool live = t < Tb;
-#pragma unroll
-                for (int n1 = 0; n1 < 8; ++n1) {
-                    int i0 = reflect(base + 50 * n1, N), i1 = reflect(base + 50 * n1 + 1, N);
-                    i0 = min(max(i0, 0), N - 1);
-                    i1 = min(max(i1, 0), N - 1);
-                    const float v0 = pcm(x, i0), v1 = pcm(x, i1);
-                    xs[p][2 * n1] = live ? v0 : 0.f;
-                    xs[p][2 * n1 + 1] = live ? v1 : 0.f;
-                }
-            }
-        }
         float2 w[8];
         cf tw[8];
 #pragma unroll
         for (int n1 = 0; n1 < 8; ++n1) w[n1] = *reinterpret_cast<const float2*>(&plan->win[50 * n1 + 2 * n2]);
 #pragma unroll
         for (int k1 = 1; k1 < 8; ++k1) tw[k1] = plan->tw200[n2][k1];
+        const char* src = L + fh * (kHop * 4) + n2 * 8;
+        char* dst = L + fh * (kZStride * 8) + n2 * 8;
+        __builtin_amdgcn_wave_barrier();
 #pragma unroll
-        for (int p = 0; p < 4; ++p) {
-            const int f = 2 * p + fh;
+        for (int pp = 0; pp < 4; ++pp) {
+            const int p = 3 - pp;
             cf z[8];
 #pragma unroll
-            for (int n1 = 0; n1 < 8; ++n1) z[n1] = mk(xs[p][2 * n1] * w[n1].x, xs[p][2 * n1 + 1] * w[n1].y);
+            for (int n1 = 0; n1 < 8; ++n1) {
+                const cf xs = ld2(src + p * (2 * kHop * 4) + n1 * 200);
+                z[n1] = mk(xs.re * w[n1].x, xs.im * w[n1].y);
+            }
             dft8(z);
             if (active) {
-                L.yz[f][n2] = z[0];
+                st2(dst + p * (2 * kZStride * 8), z[0]);
 #pragma unroll
-                for (int k1 = 1; k1 < 8; ++k1) L.yz[f][k1 * 25 + n2] = mul(z[k1], tw[k1]);
+                for (int k1 = 1; k1 < 8; ++k1) st2(dst + p * (2 * kZStride * 8) + k1 * 200, mul(z[k1], tw[k1]));
             }
         }
     }
@@ -149,105 +154,136 @@ __global__ __launch_bounds__(64 * kWPB, 3) void melspec_kernel(
     // ------------------------------------------------------------------ phase 2
     {
         const int f = lane >> 3, k1 = lane & 7;
+        char* base = L + f * (kZStride * 8);
         cf y[25];
 #pragma unroll
-        for (int n2 = 0; n2 < 25; ++n2) y[n2] = L.yz[f][k1 * 25 + n2];
+        for (int n2 = 0; n2 < 25; ++n2) y[n2] = ld2(base + (k1 * 25 + n2) * 8);
         dft25(y);
-        __builtin_amdgcn_wave_barrier();
 #pragma unroll
-        for (int k2 = 0; k2 < 25; ++k2) L.yz[f][k1 + 8 * k2] = y[k2];
+        for (int k2 = 0; k2 < 25; ++k2) st2(base + (k1 + 8 * k2) * 8, y[k2]);
     }
     __builtin_amdgcn_wave_barrier();
 
     // ------------------------------------------------------------------ phase 3
-    // 808 lane-tasks (frame, k <= 100) in 13 passes.  Every pass's two spectrum points and its
-    // twiddle are read first; only then do the magnitudes overwrite the same LDS bytes.
+    // Frame by frame, lane = bin: k = lane and k = 64 + lane (37 lanes) with their mirror bins 200 - k; the
+    // next frame's four points are read before this frame's magnitudes are written.
     {
-        constexpr int NP = 13;
-        cf zk[NP], zm[NP], tw[NP];
+        const int kA = lane, kB = min(64 + lane, 100);
+        const bool actB = lane < 37;
+        const cf twA = plan->tw400[kA], twB = plan->tw400[kB];
+        const int mA = (kA == 0 ? 0 : 200 - kA) * 8;   // Z[200] := Z[0]
+        cf zkA = ld2(L + kA * 8), zmA = ld2(L + mA);
+        cf zkB = ld2(L + kB * 8), zmB = ld2(L + (200 - kB) * 8);
 #pragma unroll
-        for (int q = 0; q < NP; ++q) {
-            const int task = min(q * 64 + lane, kF * 101 - 1);
-            const int f = task / 101, k = task - f * 101;
-            const int km = (k == 0) ? 0 : 200 - k;
-            zk[q] = L.yz[f][k];
-            zm[q] = L.yz[f][km];
-            tw[q] = plan->tw400[k];
-        }
-        __builtin_amdgcn_wave_barrier();
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // all reads landed before the aliasing writes
-        __builtin_amdgcn_wave_barrier();
-#pragma unroll
-        for (int q = 0; q < NP; ++q) {
-            const int task = q * 64 + lane;
-            const int tk = min(task, kF * 101 - 1);
-            const int f = tk / 101, k = tk - f * 101;
-            float mk_, mm_;
-            real_post(zk[q], zm[q], tw[q], mk_, mm_);
-            if (task < kF * 101) {
-                L.mag[f][k] = mk_;
-                L.mag[f][200 - k] = mm_;
+        for (int f = 0; f < kF; ++f) {
+            const cf ckA = zkA, cmA = zmA, ckB = zkB, cmB = zmB;
+            if (f + 1 < kF) {
+                const char* nb = L + (f + 1) * (kZStride * 8);
+                zkA = ld2(nb + kA * 8); zmA = ld2(nb + mA);
+                zkB = ld2(nb + kB * 8); zmB = ld2(nb + (200 - kB) * 8);
+            }
+            float m0, m1, m2, m3;
+            real_post(ckA, cmA, twA, m0, m1);
+            real_post(ckB, cmB, twB, m2, m3);
+            char* mrow = L + f * (kMagStride * 4);
+            st1(mrow + kA * 4, m0);
+            st1(mrow + (200 - kA) * 4, m1);
+            if (actB) {
+                st1(mrow + kB * 4, m2);
+                st1(mrow + (200 - kB) * 4, m3);
             }
         }
     }
-    __builtin_amdgcn_wave_barrier();
+}
+
+template <typename S>
+__global__ __launch_bounds__(64 * kWPB, 3) void melspec_kernel(
+    const S* __restrict__ wav, const int64_t* __restrict__ offs, int T_max,
+    const MelPlan* __restrict__ plan, const int32_t* __restrict__ masks, int flags,
+    float* __restrict__ out) {
+    __shared__ __attribute__((aligned(16))) char s_lds[kWPB][kWaveLdsBytes];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    char* L = s_lds[wave];
+    const int b = blockIdx.y;
+    const int t0 = (blockIdx.x * kWPB + wave) * kF;
+    const int tp = (blockIdx.x * kWPB + (wave & ~1)) * kF;   // first frame of the wave pair
+    // A pair leaves together (a finished wave no longer counts at the workgroup barrier below).
+    if (tp >= T_max) return;
+    const int64_t off = offs[b];
+    const int N = (int)(offs[b + 1] - off);
+    const int Tb = N > 0 ? 1 + N / kHop : 0;
+    const S* x = wav + off;
+    float* outb = out + (int64_t)b * kMels * T_max;
+
+    if (tp >= Tb) {  // pure padding: zeros
+        for (int i = lane; i < kMels * kF; i += 64) {
+            const int m = i >> 3, f = i & 7;
+            if (t0 + f < T_max) outb[(int64_t)m * T_max + t0 + f] = 0.f;
+        }
+        return;
+    }
+    // A wave past the utterance's (or the batch's) last frame beside a live partner skips the transforms: its
+    // columns of the projection hold whatever its LDS rows held and are masked / not stored.
+    const bool live = t0 < Tb && t0 < T_max;
+
+    int mf0 = 0, mfw = 0, mt0 = 0, mtw = 0;
+    if (masks) {
+        mf0 = masks[b * 4 + 0]; mfw = masks[b * 4 + 1];
+        mt0 = masks[b * 4 + 2]; mtw = masks[b * 4 + 3];
+    }
+    // this wave's share of the projection: slots [slot_beg, slot_end); its first group of filterbank images is
+    // requested here, three phases ahead of its use
+    const int par = wave & 1;
+    const int slot_beg = par ? plan->split : 0, slot_end = par ? kTiles : plan->split;
+    const float* a_ptr = plan->fbt[plan->slot_blk0[slot_beg]] + lane;
+    float a_cur[kGroup];
+#pragma unroll
+    for (int r = 0; r < kGroup; ++r) a_cur[r] = a_ptr[64 * r];
+
+    if (live) transform_frames(x, N, t0, plan, L, lane);
+    __syncthreads();   // both magnitude images of the pair are complete
 
     // ------------------------------------------------------------------ phases 4 + 5
-    // One flat pass over the non-zero 4-bin blocks of all five 16-mel tiles (they are contiguous in
-    // plan->fbt), A operands running eight MFMAs ahead in a register ring across tile boundaries;
-    // a tile's 16 x 8 outputs are masked and stored when its last block has been accumulated.
+    // Mel projection on the matrix cores: a tile is 16 mels x the PAIR's 16 frames (columns 0-7 from the even
+    // wave's magnitudes, 8-15 from the odd wave's), over the tile's non-zero 4-bin blocks only: per block one
+    // coalesced 256-byte image load (requested a group ahead; a wave's images are contiguous, so the request runs
+    // across tile boundaries), one LDS read and one v_mfma_f32_16x16x4_f32; then the tile's 16 x 16 outputs are
+    // masked and stored, 64 bytes per mel row.
     {
         const int fcol = lane & 15, kq = lane >> 4;
-        const float* magrow = L.mag[fcol & 7];
-        const int t = t0 + (fcol & 7);
+        const char* magrow = s_lds[(wave & ~1) + (fcol >> 3)] + (fcol & 7) * (kMagStride * 4) + kq * 4;
+        const int t = tp + fcol;
         const bool tmask = (t >= Tb) || (t >= mt0 && t < mt0 + mtw);
-        const bool store_lane = fcol < kF && t < T_max;
-        int tnb[kTiles], tk0[kTiles];
+        const bool store_lane = t < T_max;
+        // one unsigned compare per value: (mel - mf0) < mfw; a masked frame makes every mel fall inside
+        const int melb = kq * 4 - (tmask ? -(1 << 20) : mf0);
+        const unsigned mlim = tmask ? 0x7fffffffu : (unsigned)mfw;
+        float* orow = outb + (int64_t)(kq * 4) * T_max + t;
+        for (int slot = slot_beg; slot < slot_end; ++slot) {
+            const int nb = plan->slot_nblk[slot], tile = plan->slot_tile[slot];
+            const char* bp = magrow + plan->slot_k0[slot] * 4;
+            f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+            for (int i = 0; i < nb; i += kGroup) {
+                a_ptr += 64 * kGroup;
+                float a_nxt[kGroup], bv[kGroup];
 #pragma unroll
-        for (int i = 0; i < kTiles; ++i) { tnb[i] = plan->tile_nblk[i]; tk0[i] = plan->tile_k0[i]; }
-        const int total = plan->tile_blk0[kTiles - 1] + tnb[kTiles - 1];
-        const float* a_img = plan->fbt[0] + lane;
-        constexpr int RING = 8;
-        float ar[RING];
+                for (int r = 0; r < kGroup; ++r) a_nxt[r] = a_ptr[64 * r];
 #pragma unroll
-        for (int r = 0; r < RING; ++r) ar[r] = a_img[min(r, max(total - 1, 0)) * 64];
-        f32x4 acc = {0.f, 0.f, 0.f, 0.f};
-        int tile = 0, left = tnb[0], kbase = tk0[0];
-        auto flush = [&]() {
+                for (int r = 0; r < kGroup; ++r) bv[r] = *reinterpret_cast<const lds_f1*>(bp + 16 * r);
+                bp += 16 * kGroup;
+#pragma unroll
+                for (int r = 0; r < kGroup; ++r) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a_cur[r], bv[r], acc, 0, 0, 0);
+#pragma unroll
+                for (int r = 0; r < kGroup; ++r) a_cur[r] = a_nxt[r];
+            }
             if (store_lane) {
+                float* o = orow + (int64_t)(tile * 16) * T_max;
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
-                    const int mel = tile * 16 + kq * 4 + r;
                     float v = acc[r];
                     if (flags & 1) v = logf(v + 1e-6f);
-                    if (tmask || (mel >= mf0 && mel < mf0 + mfw)) v = 0.f;
-                    outb[(int64_t)mel * T_max + t] = v;
-                }
-            }
-            acc = f32x4{0.f, 0.f, 0.f, 0.f};
-            ++tile;
-            // tile metadata by select chain (register arrays must not be indexed at run time)
-            int nb = 0, k0n = 0;
-#pragma unroll
-            for (int i = 1; i < kTiles; ++i) { nb = tile == i ? tnb[i] : nb; k0n = tile == i ? tk0[i] : k0n; }
-            left = nb;
-            kbase = k0n;
-        };
-        while (tile < kTiles && left == 0) flush();   // leading all-zero tiles
-        for (int g0 = 0; g0 < total; g0 += RING) {
-#pragma unroll
-            for (int r = 0; r < RING; ++r) {
-                const int g = g0 + r;
-                const float av = ar[r];
-                ar[r] = a_img[min(g + RING, total - 1) * 64];   // eight MFMAs ahead
-                if (g < total) {
-                    const float bv = magrow[min(kbase + kq, kBins - 1)];
-                    acc = __builtin_amdgcn_mfma_f32_16x16x4f32(av, bv, acc, 0, 0, 0);
-                    kbase += 4;
-                    if (--left == 0) {
-                        flush();
-                        while (tile < kTiles && left == 0) flush();   // all-zero tiles store zeros
-                    }
+                    if ((unsigned)(melb + tile * 16 + r) < mlim) v = 0.f;
+                    o[(int64_t)r * T_max] = v;
                 }
             }
         }
@@ -305,7 +341,9 @@ extern "C" int sp_melspec_plan(const float* fbank_host, void* plan_dev, void* st
         const double a = two_pi * (double)k / 400.0;
         hp.tw400[k] = melmath::mk((float)std::cos(a), (float)-std::sin(a));
     }
-    int blk = 0;
+    // per tile: the bins its 16 filters touch, in whole groups of 4-bin blocks; the window is moved down rather
+    // than past the last bin where it can be (bins 201..203 of a row are finite leftovers that meet zero rows)
+    int t_k0[kTiles], t_nblk[kTiles];
     for (int tile = 0; tile < kTiles; ++tile) {
         int lo = kBins, hi = -1;
         for (int f = 0; f < kBins; ++f)
@@ -314,15 +352,41 @@ extern "C" int sp_melspec_plan(const float* fbank_host, void* plan_dev, void* st
                     lo = f < lo ? f : lo;
                     hi = f > hi ? f : hi;
                 }
-        hp.tile_blk0[tile] = blk;
-        hp.tile_k0[tile] = hi < 0 ? 0 : lo;
-        hp.tile_nblk[tile] = hi < 0 ? 0 : (hi - lo + 4) / 4;
-        for (int kb = 0; kb < hp.tile_nblk[tile]; ++kb, ++blk)
-            for (int l = 0; l < 64; ++l) {
-                const int f = lo + 4 * kb + (l >> 4), m = 16 * tile + (l & 15);
-                hp.fbt[blk][l] = f < kBins ? fbank_host[f * kMels + m] : 0.f;
-            }
+        int nblk = hi < 0 ? 0 : (hi - lo + 4) / 4;
+        nblk = (nblk + kGroup - 1) / kGroup * kGroup;
+        int k0 = hi < 0 ? 0 : lo;
+        if (k0 + 4 * nblk > kBins) k0 = kBins - 4 * nblk > 0 ? kBins - 4 * nblk : 0;
+        t_k0[tile] = k0;
+        t_nblk[tile] = nblk;
     }
+    // deal the tiles to the pair's two waves: the subset whose block count is nearest to half
+    int best = 0, best_diff = 1 << 30, total = 0;
+    for (int tile = 0; tile < kTiles; ++tile) total += t_nblk[tile];
+    for (int sub = 0; sub < (1 << kTiles); ++sub) {
+        int n = 0;
+        for (int tile = 0; tile < kTiles; ++tile) n += (sub >> tile & 1) ? t_nblk[tile] : 0;
+        const int diff = n * 2 > total ? n * 2 - total : total - n * 2;
+        if (diff < best_diff) { best_diff = diff; best = sub; }
+    }
+    int blk = 0, slot = 0;
+    for (int side = 0; side < 2; ++side) {
+        for (int tile = 0; tile < kTiles; ++tile) {
+            if (((best >> tile) & 1) != (side == 0)) continue;
+            hp.slot_tile[slot] = tile;
+            hp.slot_k0[slot] = t_k0[tile];
+            hp.slot_nblk[slot] = t_nblk[tile];
+            hp.slot_blk0[slot] = blk;
+            for (int kb = 0; kb < t_nblk[tile]; ++kb, ++blk)
+                for (int l = 0; l < 64; ++l) {
+                    const int f = t_k0[tile] + 4 * kb + (l >> 4), m = 16 * tile + (l & 15);
+                    hp.fbt[blk][l] = f < kBins ? fbank_host[f * kMels + m] : 0.f;
+                }
+            ++slot;
+        }
+        if (side == 0) hp.split = slot;
+        blk += kGroup;   // zero images the look-ahead of the wave's last group lands on
+    }
+    for (; slot < 8; ++slot) hp.slot_blk0[slot] = blk - kGroup;   // an empty share still requests one (zero) group
     hipError_t e = hipMemcpyAsync(plan_dev, &hp, sizeof(hp), hipMemcpyHostToDevice,
                                   reinterpret_cast<hipStream_t>(stream));
     if (e != hipSuccess) return fail(SP_ELAUNCH, "sp_melspec_plan: %s", hipGetErrorString(e));

@@ -28,8 +28,8 @@ constexpr int kWPB = 4;           // waves per block
 constexpr int kZStride = 200;     // complex points per frame (1600 B: the 25-point transforms' reads are conflict-free)
 constexpr int kMagStride = 201;   // odd stride: conflict-free column reads
 constexpr int kTiles = kMels / 16;
-constexpr int kGroup = 2;         // 4-bin blocks per trip of the projection loop
-constexpr int kMaxBlk = kTiles * 52 + 2 * kGroup;
+constexpr int kGroup = 4;         // 4-bin blocks per trip of the projection loop
+constexpr int kMaxBlk = kTiles * 52 + 4 * kGroup;
 constexpr int kStage = (kF - 1) * kHop + kNfft;   // samples a wave's 8 frames touch: 1520
 
 struct MelPlan {
@@ -44,8 +44,8 @@ struct MelPlan {
     int slot_blk0[8];  // first image of the slot in fbt
     int split;
     int pad_[3];
-    // A operand images in slot order, kGroup all-zero blocks after each wave's share (the loop requests one
-    // group ahead): lane l -> fb[k0 + 4 blk + (l>>4)][16 tile + (l&15)]
+    // A operand images in slot order, two groups of all-zero blocks after each wave's share (the loop requests
+    // two groups ahead): lane l -> fb[k0 + 4 blk + (l>>4)][16 tile + (l&15)]
     float fbt[kMaxBlk][64];
 };
 
@@ -70,17 +70,92 @@ constexpr int kWaveLdsBytes = kF * kZStride * 8 + 64;   // + 16 banks: the pair'
 static_assert(2 * kZStride * 8 >= (kHop + kNfft) * 4, "pass 1 writes above the samples pass 0 still needs");
 static_assert(kWaveLdsBytes % 16 == 0, "16-byte staging stores");
 
-__device__ __forceinline__ cf ld2(const char* p) {
-    const f32x2 v = *reinterpret_cast<const lds_f2*>(p);
-    return mk(v.x, v.y);
+// ---- packed complex arithmetic ------------------------------------------------------------------------
+// A complex number is a register pair (re, im) and every butterfly is ONE v_pk_*_f32: a wave issues an
+// instruction every ~5 cycles whatever it is (tools/ubench/valu_tput.hip), so at the three waves per SIMD the
+// LDS footprint allows, the instruction count, not the flop count, is what the transform costs.  The compiler
+// packs plain adds and scalar multiples by itself; multiplications by +-i and conjugations need the
+// op_sel / neg modifiers, which it does not fold (it emits v_xor + v_mov), hence the asm helpers.  The scalar
+// forms of the same transforms live in mel_math.h (host replay: tests/host/mel_emulate.cpp).
+using c2 = f32x2;
+#define SP_PK2(name, text)                                        \
+    __device__ __forceinline__ c2 name(c2 a, c2 b) {              \
+        c2 d;                                                     \
+        asm(text : "=v"(d) : "v"(a), "v"(b));                     \
+        return d;                                                 \
+    }
+SP_PK2(add_mi, "v_pk_add_f32 %0, %1, %2 op_sel:[0,1] op_sel_hi:[1,0] neg_hi:[0,1]")     // a + (-i) b
+SP_PK2(add_pi, "v_pk_add_f32 %0, %1, %2 op_sel:[0,1] op_sel_hi:[1,0] neg_lo:[0,1]")     // a + i b
+SP_PK2(add_conj, "v_pk_add_f32 %0, %1, %2 neg_hi:[0,1]")                                // a + conj(b)
+SP_PK2(sub_conj, "v_pk_add_f32 %0, %1, %2 neg_lo:[0,1]")                                // a - conj(b)
+#undef SP_PK2
+// a * w: (a.im w.im, a.im w.re), then (a.re w.re - ., a.re w.im + .)
+__device__ __forceinline__ c2 cmul(c2 a, c2 w) {
+    c2 t, d;
+    asm("v_pk_mul_f32 %0, %1, %2 op_sel:[1,1] op_sel_hi:[1,0]" : "=v"(t) : "v"(a), "v"(w));
+    asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel_hi:[0,1,1] neg_lo:[0,0,1]" : "=v"(d) : "v"(a), "v"(w), "v"(t));
+    return d;
 }
-__device__ __forceinline__ void st2(char* p, cf v) {
-    f32x2 t;
-    t.x = v.re;
-    t.y = v.im;
-    *reinterpret_cast<lds_f2*>(p) = t;
+// the same with a compile-time constant w held in a scalar register pair
+__device__ __forceinline__ c2 cmul_k(c2 a, float wre, float wim) {
+    const c2 w = {wre, wim};
+    c2 t, d;
+    asm("v_pk_mul_f32 %0, %1, %2 op_sel:[1,1] op_sel_hi:[1,0]" : "=v"(t) : "v"(a), "s"(w));
+    asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel_hi:[0,1,1] neg_lo:[0,0,1]" : "=v"(d) : "v"(a), "s"(w), "v"(t));
+    return d;
 }
+
+// forward 8-point DFT in place (mel_math.h dft8)
+__device__ __forceinline__ void dft8_pk(c2 (&z)[8]) {
+    const c2 a0 = z[0] + z[4], a4 = z[0] - z[4], a1 = z[1] + z[5], a5 = z[1] - z[5];
+    const c2 a2 = z[2] + z[6], a6 = z[2] - z[6], a3 = z[3] + z[7], a7 = z[3] - z[7];
+    const c2 b0 = a0 + a2, b2 = a0 - a2, b1 = a1 + a3, b3 = a1 - a3;
+    z[0] = b0 + b1; z[4] = b0 - b1; z[2] = add_mi(b2, b3); z[6] = add_pi(b2, b3);
+    const c2 c1 = add_mi(a5, a5) * kInvSqrt2;      // a5 (1 - i) / sqrt 2
+    const c2 c3 = add_pi(a7, a7) * -kInvSqrt2;     // a7 (-1 - i) / sqrt 2
+    const c2 d0 = add_mi(a4, a6), d2 = add_pi(a4, a6);
+    const c2 d1 = c1 + c3, d3 = c1 - c3;
+    z[1] = d0 + d1; z[5] = d0 - d1; z[3] = add_mi(d2, d3); z[7] = add_pi(d2, d3);
+}
+
+// forward 5-point DFT (mel_math.h dft5): 18 packed instructions
+__device__ __forceinline__ void dft5_pk(c2 x0, c2 x1, c2 x2, c2 x3, c2 x4, c2& y0, c2& y1, c2& y2, c2& y3, c2& y4) {
+    const c2 t1 = x1 + x4, t2 = x2 + x3, t3 = x1 - x4, t4 = x2 - x3;
+    y0 = x0 + t1 + t2;
+    const c2 a1 = x0 + kC1 * t1 + kC2 * t2, a2 = x0 + kC2 * t1 + kC1 * t2;
+    const c2 b1 = kS1 * t3 + kS2 * t4, b2 = kS2 * t3 - kS1 * t4;
+    y1 = add_mi(a1, b1); y4 = add_pi(a1, b1);
+    y2 = add_mi(a2, b2); y3 = add_pi(a2, b2);
+}
+
+// forward 25-point DFT in place (mel_math.h dft25)
+__device__ __forceinline__ void dft25_pk(c2 (&y)[25]) {
+    constexpr float twre[4][4] = SP_TW25_RE;
+    constexpr float twim[4][4] = SP_TW25_IM;
+    c2 g[5][5];
+#pragma unroll
+    for (int b = 0; b < 5; ++b) dft5_pk(y[b], y[5 + b], y[10 + b], y[15 + b], y[20 + b], g[b][0], g[b][1], g[b][2], g[b][3], g[b][4]);
+#pragma unroll
+    for (int b = 1; b < 5; ++b)
+#pragma unroll
+        for (int c = 1; c < 5; ++c) g[b][c] = cmul_k(g[b][c], twre[b - 1][c - 1], twim[b - 1][c - 1]);
+#pragma unroll
+    for (int c = 0; c < 5; ++c) dft5_pk(g[0][c], g[1][c], g[2][c], g[3][c], g[4][c], y[c], y[c + 5], y[c + 10], y[c + 15], y[c + 20]);
+}
+
+// real-FFT split for one bin pair (mel_math.h real_post) WITHOUT its two halvings: from Zk = Z[k], Zm = Z[200-k]
+// and w = W400^k, 2|X[k]| and 2|X[200-k]| (the filterbank images carry the factor 1/2, exactly)
+__device__ __forceinline__ void real_post_pk(c2 Zk, c2 Zm, c2 w, float& mag_k, float& mag_m) {
+    const c2 E = add_conj(Zk, Zm), P = cmul(sub_conj(Zk, Zm), w);
+    const c2 xa = add_mi(E, P), xb = add_pi(E, P);
+    mag_k = __builtin_amdgcn_sqrtf(fmaf(xa.y, xa.y, xa.x * xa.x));
+    mag_m = __builtin_amdgcn_sqrtf(fmaf(xb.y, xb.y, xb.x * xb.x));
+}
+
+__device__ __forceinline__ c2 ld2(const char* p) { return *reinterpret_cast<const lds_f2*>(p); }
+__device__ __forceinline__ void st2(char* p, c2 v) { *reinterpret_cast<lds_f2*>(p) = v; }
 __device__ __forceinline__ void st1(char* p, float v) { *reinterpret_cast<lds_f1*>(p) = v; }
+__device__ __forceinline__ c2 ldg2(const void* p) { return *reinterpret_cast<const c2*>(p); }
 
 // S = sample type: float in [-1, 1], or int16_t PCM read as sample / 32768 (exact in f32: what
 // torchaudio.load(normalize=True) hands the reference for 16-bit files) -- half the bytes to read.
@@ -123,29 +198,25 @@ __device__ __forceinline__ void transform_frames(const S* __restrict__ x, int N,
         const int fh = lane >= 25 ? 1 : 0;
         const int n2 = min(lane - 25 * fh, 24);
         const bool active = lane < 50;
-        float2 w[8];
-        cf tw[8];
+        c2 w[8], tw[8];
 #pragma unroll
-        for (int n1 = 0; n1 < 8; ++n1) w[n1] = *reinterpret_cast<const float2*>(&plan->win[50 * n1 + 2 * n2]);
+        for (int n1 = 0; n1 < 8; ++n1) w[n1] = ldg2(&plan->win[50 * n1 + 2 * n2]);
 #pragma unroll
-        for (int k1 = 1; k1 < 8; ++k1) tw[k1] = plan->tw200[n2][k1];
+        for (int k1 = 1; k1 < 8; ++k1) tw[k1] = ldg2(&plan->tw200[n2][k1]);
         const char* src = L + fh * (kHop * 4) + n2 * 8;
         char* dst = L + fh * (kZStride * 8) + n2 * 8;
         __builtin_amdgcn_wave_barrier();
 #pragma unroll
         for (int pp = 0; pp < 4; ++pp) {
             const int p = 3 - pp;
-            cf z[8];
+            c2 z[8];
 #pragma unroll
-            for (int n1 = 0; n1 < 8; ++n1) {
-                const cf xs = ld2(src + p * (2 * kHop * 4) + n1 * 200);
-                z[n1] = mk(xs.re * w[n1].x, xs.im * w[n1].y);
-            }
-            dft8(z);
+            for (int n1 = 0; n1 < 8; ++n1) z[n1] = ld2(src + p * (2 * kHop * 4) + n1 * 200) * w[n1];
+            dft8_pk(z);
             if (active) {
                 st2(dst + p * (2 * kZStride * 8), z[0]);
 #pragma unroll
-                for (int k1 = 1; k1 < 8; ++k1) st2(dst + p * (2 * kZStride * 8) + k1 * 200, mul(z[k1], tw[k1]));
+                for (int k1 = 1; k1 < 8; ++k1) st2(dst + p * (2 * kZStride * 8) + k1 * 200, cmul(z[k1], tw[k1]));
             }
         }
     }
@@ -155,10 +226,10 @@ __device__ __forceinline__ void transform_frames(const S* __restrict__ x, int N,
     {
         const int f = lane >> 3, k1 = lane & 7;
         char* base = L + f * (kZStride * 8);
-        cf y[25];
+        c2 y[25];
 #pragma unroll
         for (int n2 = 0; n2 < 25; ++n2) y[n2] = ld2(base + (k1 * 25 + n2) * 8);
-        dft25(y);
+        dft25_pk(y);
 #pragma unroll
         for (int k2 = 0; k2 < 25; ++k2) st2(base + (k1 + 8 * k2) * 8, y[k2]);
     }
@@ -170,21 +241,21 @@ __device__ __forceinline__ void transform_frames(const S* __restrict__ x, int N,
     {
         const int kA = lane, kB = min(64 + lane, 100);
         const bool actB = lane < 37;
-        const cf twA = plan->tw400[kA], twB = plan->tw400[kB];
+        const c2 twA = ldg2(&plan->tw400[kA]), twB = ldg2(&plan->tw400[kB]);
         const int mA = (kA == 0 ? 0 : 200 - kA) * 8;   // Z[200] := Z[0]
-        cf zkA = ld2(L + kA * 8), zmA = ld2(L + mA);
-        cf zkB = ld2(L + kB * 8), zmB = ld2(L + (200 - kB) * 8);
+        c2 zkA = ld2(L + kA * 8), zmA = ld2(L + mA);
+        c2 zkB = ld2(L + kB * 8), zmB = ld2(L + (200 - kB) * 8);
 #pragma unroll
         for (int f = 0; f < kF; ++f) {
-            const cf ckA = zkA, cmA = zmA, ckB = zkB, cmB = zmB;
+            const c2 ckA = zkA, cmA = zmA, ckB = zkB, cmB = zmB;
             if (f + 1 < kF) {
                 const char* nb = L + (f + 1) * (kZStride * 8);
                 zkA = ld2(nb + kA * 8); zmA = ld2(nb + mA);
                 zkB = ld2(nb + kB * 8); zmB = ld2(nb + (200 - kB) * 8);
             }
             float m0, m1, m2, m3;
-            real_post(ckA, cmA, twA, m0, m1);
-            real_post(ckB, cmB, twB, m2, m3);
+            real_post_pk(ckA, cmA, twA, m0, m1);
+            real_post_pk(ckB, cmB, twB, m2, m3);
             char* mrow = L + f * (kMagStride * 4);
             st1(mrow + kA * 4, m0);
             st1(mrow + (200 - kA) * 4, m1);
@@ -202,8 +273,9 @@ __global__ __launch_bounds__(64 * kWPB, 3) void melspec_kernel(
     const MelPlan* __restrict__ plan, const int32_t* __restrict__ masks, int flags,
     float* __restrict__ out) {
     __shared__ __attribute__((aligned(16))) char s_lds[kWPB][kWaveLdsBytes];
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    char* L = s_lds[wave];
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);   // uniform: frame ranges, slots and the plan's
+    char* L = s_lds[wave];                                               // fields stay in scalar registers
     const int b = blockIdx.y;
     const int t0 = (blockIdx.x * kWPB + wave) * kF;
     const int tp = (blockIdx.x * kWPB + (wave & ~1)) * kF;   // first frame of the wave pair
@@ -236,9 +308,12 @@ __global__ __launch_bounds__(64 * kWPB, 3) void melspec_kernel(
     const int par = wave & 1;
     const int slot_beg = par ? plan->split : 0, slot_end = par ? kTiles : plan->split;
     const float* a_ptr = plan->fbt[plan->slot_blk0[slot_beg]] + lane;
-    float a_cur[kGroup];
+    float a_cur[kGroup], a_nx1[kGroup];
 #pragma unroll
     for (int r = 0; r < kGroup; ++r) a_cur[r] = a_ptr[64 * r];
+#pragma unroll
+    for (int r = 0; r < kGroup; ++r) a_nx1[r] = a_ptr[64 * (kGroup + r)];
+    a_ptr += 64 * kGroup;
 
     if (live) transform_frames(x, N, t0, plan, L, lane);
     __syncthreads();   // both magnitude images of the pair are complete
@@ -246,7 +321,7 @@ __global__ __launch_bounds__(64 * kWPB, 3) void melspec_kernel(
     // ------------------------------------------------------------------ phases 4 + 5
     // Mel projection on the matrix cores: a tile is 16 mels x the PAIR's 16 frames (columns 0-7 from the even
     // wave's magnitudes, 8-15 from the odd wave's), over the tile's non-zero 4-bin blocks only: per block one
-    // coalesced 256-byte image load (requested a group ahead; a wave's images are contiguous, so the request runs
+    // coalesced 256-byte image load (requested two groups ahead; a wave's images are contiguous, so the request runs
     // across tile boundaries), one LDS read and one v_mfma_f32_16x16x4_f32; then the tile's 16 x 16 outputs are
     // masked and stored, 64 bytes per mel row.
     {
@@ -265,26 +340,25 @@ __global__ __launch_bounds__(64 * kWPB, 3) void melspec_kernel(
             f32x4 acc = {0.f, 0.f, 0.f, 0.f};
             for (int i = 0; i < nb; i += kGroup) {
                 a_ptr += 64 * kGroup;
-                float a_nxt[kGroup], bv[kGroup];
+                float a_nx2[kGroup], bv[kGroup];
 #pragma unroll
-                for (int r = 0; r < kGroup; ++r) a_nxt[r] = a_ptr[64 * r];
+                for (int r = 0; r < kGroup; ++r) a_nx2[r] = a_ptr[64 * r];
 #pragma unroll
                 for (int r = 0; r < kGroup; ++r) bv[r] = *reinterpret_cast<const lds_f1*>(bp + 16 * r);
                 bp += 16 * kGroup;
 #pragma unroll
                 for (int r = 0; r < kGroup; ++r) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a_cur[r], bv[r], acc, 0, 0, 0);
 #pragma unroll
-                for (int r = 0; r < kGroup; ++r) a_cur[r] = a_nxt[r];
+                for (int r = 0; r < kGroup; ++r) { a_cur[r] = a_nx1[r]; a_nx1[r] = a_nx2[r]; }
             }
             if (store_lane) {
                 float* o = orow + (int64_t)(tile * 16) * T_max;
+                if (flags & 1) {
 #pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    float v = acc[r];
-                    if (flags & 1) v = logf(v + 1e-6f);
-                    if ((unsigned)(melb + tile * 16 + r) < mlim) v = 0.f;
-                    o[(int64_t)r * T_max] = v;
+                    for (int r = 0; r < 4; ++r) acc[r] = logf(acc[r] + 1e-6f);
                 }
+#pragma unroll
+                for (int r = 0; r < 4; ++r) o[(int64_t)r * T_max] = (unsigned)(melb + tile * 16 + r) < mlim ? 0.f : acc[r];
             }
         }
     }
@@ -379,14 +453,14 @@ extern "C" int sp_melspec_plan(const float* fbank_host, void* plan_dev, void* st
             for (int kb = 0; kb < t_nblk[tile]; ++kb, ++blk)
                 for (int l = 0; l < 64; ++l) {
                     const int f = t_k0[tile] + 4 * kb + (l >> 4), m = 16 * tile + (l & 15);
-                    hp.fbt[blk][l] = f < kBins ? fbank_host[f * kMels + m] : 0.f;
+                    hp.fbt[blk][l] = f < kBins ? 0.5f * fbank_host[f * kMels + m] : 0.f;   // phase 3 leaves 2|X|
                 }
             ++slot;
         }
         if (side == 0) hp.split = slot;
-        blk += kGroup;   // zero images the look-ahead of the wave's last group lands on
+        blk += 2 * kGroup;   // zero images the look-ahead of the wave's last groups lands on
     }
-    for (; slot < 8; ++slot) hp.slot_blk0[slot] = blk - kGroup;   // an empty share still requests one (zero) group
+    for (; slot < 8; ++slot) hp.slot_blk0[slot] = blk - 2 * kGroup;   // an empty share still requests two (zero) groups
     hipError_t e = hipMemcpyAsync(plan_dev, &hp, sizeof(hp), hipMemcpyHostToDevice,
                                   reinterpret_cast<hipStream_t>(stream));
     if (e != hipSuccess) return fail(SP_ELAUNCH, "sp_melspec_plan: %s", hipGetErrorString(e));

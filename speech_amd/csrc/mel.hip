@@ -3,17 +3,23 @@
 // Replaces data.py:15-24 and the padding of data.py:174-175 of the reference (torchaudio
 // MelSpectrogram on CPU DataLoader workers, one utterance at a time).
 //
-// Work decomposition: one WAVE owns 8 consecutive frames of one utterance and runs the whole
-// chain for them without any workgroup barrier (4 independent waves per 256-thread block, so
-// waves drift apart and overlap each other's load / VALU / LDS phases):
-//   phase 1  200 lane-tasks (frame, n2): 16 windowed samples -> 8-point DFT -> W200 twiddle -> LDS
+// Work decomposition: one WAVE owns 8 consecutive frames of one utterance and runs the transforms for them
+// without a workgroup barrier; two waves (16 frames) then share the mel projection:
+//   staging  the wave's 1520 samples, read once with coalesced 16-byte loads, into LDS
+//   phase 1  200 lane-tasks (frame, n2): 16 windowed samples -> 8-point DFT -> W200 twiddle -> LDS (in place,
+//            frame pairs from the last to the first)
 //   phase 2   64 lane-tasks (frame, k1): 25-point DFT (5x5) entirely in registers -> LDS (in place)
-//   phase 3  808 lane-tasks (frame, k<=100): real-FFT split + magnitude for bins k and 200-k -> LDS
-//   phase 4  mel projection on the matrix cores: v_mfma_f32_16x16x4_f32 (exact f32), mel x frame
-//            tiles, only over the 4-bin blocks where the 16-mel tile's filters are non-zero
-//   phase 5  masked / padded store, [B][80][T_max]
-// HBM traffic: every sample is read once from HBM (the 2.5x frame overlap is served by L1/L2),
-// every output element written once.  LDS: 12.8 KB per wave (the magnitudes alias the FFT buffer), 3 blocks per CU.
+//   phase 3  frame by frame, lane = bin k (and 64 + k): real-FFT split + magnitude for bins k and 200-k -> LDS
+//   barrier  (the only one) -- both waves of a pair have their 8 x 201 magnitudes in LDS
+//   phase 4  mel projection on the matrix cores: v_mfma_f32_16x16x4_f32 (exact f32), 16 mels x the pair's 16
+//            frames per tile, only over the 4-bin blocks where the tile's filters are non-zero; the five tiles
+//            are dealt to the pair's two waves by block count
+//   phase 5  masked / padded store, [B][80][T_max], 64 bytes per mel row and tile
+// Complex arithmetic is packed (one v_pk_*_f32 per butterfly, see below): at three waves per SIMD the kernel
+// pays per instruction issued, not per flop.
+// HBM traffic: every sample is read once from HBM (neighbouring waves' 240-sample overlap comes from L2),
+// every output element written once.  LDS: 12.9 KB per wave (samples, intermediates and magnitudes alias),
+// 3 blocks per CU.
 #include <cstring>
 
 #include "common.h"
@@ -29,7 +35,7 @@ constexpr int kZStride = 200;     // complex points per frame (1600 B: the 25-po
 constexpr int kMagStride = 201;   // odd stride: conflict-free column reads
 constexpr int kTiles = kMels / 16;
 constexpr int kGroup = 4;         // 4-bin blocks per trip of the projection loop
-constexpr int kMaxBlk = kTiles * 52 + 4 * kGroup;
+constexpr int kMaxBlk = kTiles * 52 + 6 * kGroup;
 constexpr int kStage = (kF - 1) * kHop + kNfft;   // samples a wave's 8 frames touch: 1520
 
 struct MelPlan {
@@ -43,7 +49,8 @@ struct MelPlan {
     int slot_k0[8];    // first bin of the tile's first block
     int slot_blk0[8];  // first image of the slot in fbt
     int split;
-    int pad_[3];
+    int share_groups[2];   // groups of kGroup blocks in each wave's share, even
+    int pad_;
     // A operand images in slot order, two groups of all-zero blocks after each wave's share (the loop requests
     // two groups ahead): lane l -> fb[k0 + 4 blk + (l>>4)][16 tile + (l&15)]
     float fbt[kMaxBlk][64];
@@ -170,6 +177,18 @@ __device__ __forceinline__ void transform_frames(const S* __restrict__ x, int N,
     // The wave's 1520 samples, [t0*160 - 200, (t0+7)*160 + 200), are read ONCE, coalesced, into LDS; the
     // 2.5-fold frame overlap and the stride-50 gathers of the 8-point transforms are served from there.
     // Waves at an utterance's ends (reflection, frames past the end) take the element-wise path.
+    // The lane's window taps and twiddles of phases 1 and 3 are requested first (L2 hits): the wait for the
+    // samples covers them.
+    const int fh = lane >= 25 ? 1 : 0;
+    const int n2 = min(lane - 25 * fh, 24);
+    const int kA = lane, kB = min(64 + lane, 100);
+    c2 w[8], tw[8];
+#pragma unroll
+    for (int n1 = 0; n1 < 8; ++n1) w[n1] = ldg2(&plan->win[50 * n1 + 2 * n2]);
+#pragma unroll
+    for (int k1 = 1; k1 < 8; ++k1) tw[k1] = ldg2(&plan->tw200[n2][k1]);
+    const c2 twA = ldg2(&plan->tw400[kA]), twB = ldg2(&plan->tw400[kB]);
+
     const int s0 = t0 * kHop - kNfft / 2;
     const bool interior = s0 >= 0 && s0 + kStage <= N;
     if (sizeof(S) == 4 && interior) {
@@ -195,14 +214,7 @@ __device__ __forceinline__ void transform_frames(const S* __restrict__ x, int N,
     // 200 lane-tasks (frame, n2): lane = (frame parity, n2) and 4 passes walk the frame pairs from the last to
     // the first (see the LDS note above); a lane's 16 window taps and 7 twiddles are loaded once.
     {
-        const int fh = lane >= 25 ? 1 : 0;
-        const int n2 = min(lane - 25 * fh, 24);
         const bool active = lane < 50;
-        c2 w[8], tw[8];
-#pragma unroll
-        for (int n1 = 0; n1 < 8; ++n1) w[n1] = ldg2(&plan->win[50 * n1 + 2 * n2]);
-#pragma unroll
-        for (int k1 = 1; k1 < 8; ++k1) tw[k1] = ldg2(&plan->tw200[n2][k1]);
         const char* src = L + fh * (kHop * 4) + n2 * 8;
         char* dst = L + fh * (kZStride * 8) + n2 * 8;
         __builtin_amdgcn_wave_barrier();
@@ -239,9 +251,7 @@ __device__ __forceinline__ void transform_frames(const S* __restrict__ x, int N,
     // Frame by frame, lane = bin: k = lane and k = 64 + lane (37 lanes) with their mirror bins 200 - k; the
     // next frame's four points are read before this frame's magnitudes are written.
     {
-        const int kA = lane, kB = min(64 + lane, 100);
         const bool actB = lane < 37;
-        const c2 twA = ldg2(&plan->tw400[kA]), twB = ldg2(&plan->tw400[kB]);
         const int mA = (kA == 0 ? 0 : 200 - kA) * 8;   // Z[200] := Z[0]
         c2 zkA = ld2(L + kA * 8), zmA = ld2(L + mA);
         c2 zkB = ld2(L + kB * 8), zmB = ld2(L + (200 - kB) * 8);
@@ -308,12 +318,11 @@ __global__ __launch_bounds__(64 * kWPB, 3) void melspec_kernel(
     const int par = wave & 1;
     const int slot_beg = par ? plan->split : 0, slot_end = par ? kTiles : plan->split;
     const float* a_ptr = plan->fbt[plan->slot_blk0[slot_beg]] + lane;
-    float a_cur[kGroup], a_nx1[kGroup];
+    float a_p[kGroup], a_q[kGroup];   // images of the group being multiplied and of the one after it
 #pragma unroll
-    for (int r = 0; r < kGroup; ++r) a_cur[r] = a_ptr[64 * r];
+    for (int r = 0; r < kGroup; ++r) a_p[r] = a_ptr[64 * r];
 #pragma unroll
-    for (int r = 0; r < kGroup; ++r) a_nx1[r] = a_ptr[64 * (kGroup + r)];
-    a_ptr += 64 * kGroup;
+    for (int r = 0; r < kGroup; ++r) a_q[r] = a_ptr[64 * (kGroup + r)];
 
     if (live) transform_frames(x, N, t0, plan, L, lane);
     __syncthreads();   // both magnitude images of the pair are complete
@@ -334,32 +343,44 @@ __global__ __launch_bounds__(64 * kWPB, 3) void melspec_kernel(
         const int melb = kq * 4 - (tmask ? -(1 << 20) : mf0);
         const unsigned mlim = tmask ? 0x7fffffffu : (unsigned)mfw;
         float* orow = outb + (int64_t)(kq * 4) * T_max + t;
-        for (int slot = slot_beg; slot < slot_end; ++slot) {
-            const int nb = plan->slot_nblk[slot], tile = plan->slot_tile[slot];
-            const char* bp = magrow + plan->slot_k0[slot] * 4;
-            f32x4 acc = {0.f, 0.f, 0.f, 0.f};
-            for (int i = 0; i < nb; i += kGroup) {
-                a_ptr += 64 * kGroup;
-                float a_nx2[kGroup], bv[kGroup];
+        // The wave's share is one flat run of groups (an even number of them: the plan pads); a group's images
+        // are replaced, as soon as its four MFMAs are issued, by those of the group two further on, so two
+        // register sets alternate without a copy (a copy would wait for the load it moves).
+        int slot = slot_beg;
+        const int ngroups = plan->share_groups[par];
+        int left = plan->slot_nblk[slot] / kGroup;
+        const char* bp = magrow + plan->slot_k0[slot] * 4;
+        f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+        auto group = [&](float (&a)[kGroup]) {
+            float bv[kGroup];
 #pragma unroll
-                for (int r = 0; r < kGroup; ++r) a_nx2[r] = a_ptr[64 * r];
+            for (int r = 0; r < kGroup; ++r) bv[r] = *reinterpret_cast<const lds_f1*>(bp + 16 * r);
+            bp += 16 * kGroup;
 #pragma unroll
-                for (int r = 0; r < kGroup; ++r) bv[r] = *reinterpret_cast<const lds_f1*>(bp + 16 * r);
-                bp += 16 * kGroup;
+            for (int r = 0; r < kGroup; ++r) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a[r], bv[r], acc, 0, 0, 0);
 #pragma unroll
-                for (int r = 0; r < kGroup; ++r) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a_cur[r], bv[r], acc, 0, 0, 0);
+            for (int r = 0; r < kGroup; ++r) a[r] = a_ptr[64 * (2 * kGroup + r)];
+            a_ptr += 64 * kGroup;
+            if (--left == 0) {   // the tile is complete: mask, store, next slot
+                const int tile = plan->slot_tile[slot];
+                if (store_lane) {
+                    float* o = orow + (int64_t)(tile * 16) * T_max;
+                    if (flags & 1) {
 #pragma unroll
-                for (int r = 0; r < kGroup; ++r) { a_cur[r] = a_nx1[r]; a_nx1[r] = a_nx2[r]; }
-            }
-            if (store_lane) {
-                float* o = orow + (int64_t)(tile * 16) * T_max;
-                if (flags & 1) {
+                        for (int r = 0; r < 4; ++r) acc[r] = logf(acc[r] + 1e-6f);
+                    }
 #pragma unroll
-                    for (int r = 0; r < 4; ++r) acc[r] = logf(acc[r] + 1e-6f);
+                    for (int r = 0; r < 4; ++r) o[(int64_t)r * T_max] = (unsigned)(melb + tile * 16 + r) < mlim ? 0.f : acc[r];
                 }
-#pragma unroll
-                for (int r = 0; r < 4; ++r) o[(int64_t)r * T_max] = (unsigned)(melb + tile * 16 + r) < mlim ? 0.f : acc[r];
+                acc = f32x4{0.f, 0.f, 0.f, 0.f};
+                ++slot;   // past the share's last slot the plan holds a zero-length entry that is never reached
+                left = plan->slot_nblk[slot] / kGroup;
+                bp = magrow + plan->slot_k0[slot] * 4;
             }
+        };
+        for (int g = 0; g < ngroups; g += 2) {
+            group(a_p);
+            group(a_q);
         }
     }
 }
@@ -426,7 +447,7 @@ extern "C" int sp_melspec_plan(const float* fbank_host, void* plan_dev, void* st
                     lo = f < lo ? f : lo;
                     hi = f > hi ? f : hi;
                 }
-        int nblk = hi < 0 ? 0 : (hi - lo + 4) / 4;
+        int nblk = hi < 0 ? 1 : (hi - lo + 4) / 4;   // a tile without any weight still stores its zeros
         nblk = (nblk + kGroup - 1) / kGroup * kGroup;
         int k0 = hi < 0 ? 0 : lo;
         if (k0 + 4 * nblk > kBins) k0 = kBins - 4 * nblk > 0 ? kBins - 4 * nblk : 0;
@@ -444,6 +465,7 @@ extern "C" int sp_melspec_plan(const float* fbank_host, void* plan_dev, void* st
     }
     int blk = 0, slot = 0;
     for (int side = 0; side < 2; ++side) {
+        const int blk_side = blk, slot_side = slot;
         for (int tile = 0; tile < kTiles; ++tile) {
             if (((best >> tile) & 1) != (side == 0)) continue;
             hp.slot_tile[slot] = tile;
@@ -457,8 +479,14 @@ extern "C" int sp_melspec_plan(const float* fbank_host, void* plan_dev, void* st
                 }
             ++slot;
         }
+        // an even number of groups per share: one more group of zero images for the share's last tile
+        if (slot > slot_side && ((blk - blk_side) / kGroup) % 2) {
+            hp.slot_nblk[slot - 1] += kGroup;
+            blk += kGroup;
+        }
+        hp.share_groups[side] = (blk - blk_side) / kGroup;
         if (side == 0) hp.split = slot;
-        blk += 2 * kGroup;   // zero images the look-ahead of the wave's last groups lands on
+        blk += 2 * kGroup;   // zero images the look-ahead of the share's last groups lands on
     }
     for (; slot < 8; ++slot) hp.slot_blk0[slot] = blk - 2 * kGroup;   // an empty share still requests two (zero) groups
     hipError_t e = hipMemcpyAsync(plan_dev, &hp, sizeof(hp), hipMemcpyHostToDevice,

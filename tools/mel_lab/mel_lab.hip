@@ -37,6 +37,7 @@ static void htk_fbank(std::vector<float>& fb) {
 
 int main(int argc, char** argv) {
     const int B = argc > 1 ? atoi(argv[1]) : 32, secs = argc > 2 ? atoi(argv[2]) : 15;
+    const bool i16 = argc > 3 && argv[3][0] == 'i';   // third argument "i16": feed int16 PCM (flags bit 2)
     const int N = secs * 16000, T = 1 + N / 160;
     std::vector<float> fb; htk_fbank(fb);
     std::vector<float> wav((size_t)B * N);
@@ -47,21 +48,28 @@ int main(int argc, char** argv) {
     float *d_wav, *d_out; int64_t* d_offs; void* d_plan;
     CK(hipMalloc(&d_wav, wav.size() * 4)); CK(hipMalloc(&d_out, (size_t)B * 80 * T * 4));
     CK(hipMalloc(&d_offs, offs.size() * 8)); CK(hipMalloc(&d_plan, sp_melspec_plan_bytes()));
-    CK(hipMemcpy(d_wav, wav.data(), wav.size() * 4, hipMemcpyHostToDevice));
+    if (i16) {
+        std::vector<int16_t> pcm(wav.size());
+        for (size_t i = 0; i < wav.size(); ++i) pcm[i] = (int16_t)(wav[i] * 32768.f);
+        CK(hipMemcpy(d_wav, pcm.data(), pcm.size() * 2, hipMemcpyHostToDevice));
+    } else {
+        CK(hipMemcpy(d_wav, wav.data(), wav.size() * 4, hipMemcpyHostToDevice));
+    }
+    const int fl = i16 ? 4 : 0;
     CK(hipMemcpy(d_offs, offs.data(), offs.size() * 8, hipMemcpyHostToDevice));
     if (sp_melspec_plan(fb.data(), d_plan, nullptr)) { printf("plan: %s\n", sp::err_buf()); return 1; }
     hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
     for (int i = 0; i < 5; ++i)
-        if (sp_melspec_fwd(d_wav, d_offs, B, T, d_plan, nullptr, 0, d_out, nullptr)) { printf("fwd: %s\n", sp::err_buf()); return 1; }
+        if (sp_melspec_fwd(d_wav, d_offs, B, T, d_plan, nullptr, fl, d_out, nullptr)) { printf("fwd: %s\n", sp::err_buf()); return 1; }
     CK(hipDeviceSynchronize());
     const int R = 50;
     CK(hipEventRecord(e0, nullptr));
-    for (int i = 0; i < R; ++i) sp_melspec_fwd(d_wav, d_offs, B, T, d_plan, nullptr, 0, d_out, nullptr);
+    for (int i = 0; i < R; ++i) sp_melspec_fwd(d_wav, d_offs, B, T, d_plan, nullptr, fl, d_out, nullptr);
     CK(hipEventRecord(e1, nullptr)); CK(hipEventSynchronize(e1));
     float ms = 0; CK(hipEventElapsedTime(&ms, e0, e1));
     std::vector<float> out((size_t)80 * T);
     CK(hipMemcpy(out.data(), d_out, out.size() * 4, hipMemcpyDeviceToHost));
     double cs = 0; for (float v : out) cs += v;
-    printf("%-40s B=%d T=%d  %.2f us/launch  checksum %.6e\n", LABEL, B, T, ms * 1000.0 / R, cs);
+    printf("%-32s %s B=%d T=%d  %.2f us/launch  checksum %.6e\n", LABEL, i16 ? "i16" : "f32", B, T, ms * 1000.0 / R, cs);
     return 0;
 }

@@ -142,6 +142,29 @@ def test_mel_ragged_batch_masks_padding(cuda):
     assert out.shape[-1] == 120
 
 
+def test_mel_frame_count_edges(cuda):
+    """Frame counts around the kernel's units (8 frames per wave, 16 per wave pair, 32 per workgroup; 1520 staged
+    samples per wave), padded outputs whose extra frames fall in a live wave's partner / in a pair of their own,
+    utterances whose sample offsets are odd (the 16-byte staging loads are only 4-byte aligned), f32 and int16."""
+    from speech_amd import ops
+    g = torch.Generator().manual_seed(11)
+    lens = [201, 239, 320, 321, 399, 401, 1119, 1120, 1121, 1279, 1280, 1281, 2399, 2400, 2559, 2560, 2561, 4959, 5121, 7013]
+    wavs = [(0.2 * torch.randn(n, generator=g)).clamp(-1, 1) for n in lens]
+    for chunk in (wavs[:7], wavs[7:14], wavs[14:]):
+        tb = max(1 + w.numel() // 160 for w in chunk)
+        for extra in (0, 1, 7, 8, 9, 17, 40):
+            out, ref = _mel_case(cuda, chunk, t_max=tb + extra)
+            assert out.shape[-1] == tb + extra
+            _assert_mel_close(out, ref)
+    # int16 PCM of the same utterances (odd lengths make odd sample offsets): bit-identical to the f32 path on
+    # the dequantised samples
+    pcm = [(w * 32767).round().to(torch.int16) for w in wavs]
+    offs = torch.tensor([0] + list(np.cumsum([w.numel() for w in wavs])), dtype=torch.int64)
+    a = ops.melspec(torch.cat(pcm).to(cuda), offs.to(cuda))
+    b = ops.melspec((torch.cat(pcm).float() / 32768.0).to(cuda), offs.to(cuda))
+    assert torch.equal(a, b)
+
+
 def test_mel_full_size_properties(cuda):
     """C2 size (32 x 15 s): linearity, zero padding, and agreement with the oracle on a slice."""
     from speech_amd import ops

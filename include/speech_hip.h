@@ -343,6 +343,11 @@ int sp_layernorm_bwd(const void* gy, const void* x, const float* mean, const flo
  * sp_sum_slabs_f32: out[i] (+)= scale * sum_s partials[s * slab_stride + i], i < n (n, slab_stride
  * multiples of 4; scale_dev: device float or NULL = 1) -- the reduction of split-K slabs straight into a
  * gradient buffer, with the incoming loss gradient (a device scalar) folded in.
+ *
+ * sp_linear_pack: the classifier's f32 weight [V][n] (net.py:73-76, nn.Linear(1024, n_vocab+1, bias=False)) ->
+ * its 16-bit GEMM operands in one launch: out_w [Vp][n] (rows V..Vp zero; Vp >= V, e.g. V rounded up to the 256
+ * columns the persistent kernels tile by) and / or out_t [n][Vp] = scale * W^T (scale_dev: device float or
+ * NULL = 1 -- the loss gradient that reaches the data-gradient product).  Either output may be NULL.
  * --------------------------------------------------------------------------------------- */
 int sp_gemm(const void* A, const void* B, void* C, int M, int N, int K, int64_t sam, int64_t sak,
             int64_t sbn, int64_t sbk, int64_t ldc, int in_dtype, int out_dtype, int accumulate,
@@ -350,6 +355,8 @@ int sp_gemm(const void* A, const void* B, void* C, int M, int N, int K, int64_t 
 int sp_gemm_tn_splits(int M, int N, int K, int in_dtype);
 int sp_sum_slabs_f32(const float* partials, int S, int64_t n, int64_t slab_stride, float* out,
                      int accumulate, const float* scale_dev, void* stream);
+int sp_linear_pack(const float* weight, int V, int n, int Vp, const float* scale_dev, int dtype, void* out_w,
+                   void* out_t, void* stream);
 
 #ifdef __cplusplus
 }

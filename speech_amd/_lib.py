@@ -64,6 +64,7 @@ SIGNATURES = {
     "sp_gemm": (_i, [_vp, _vp, _vp, _i, _i, _i, _i64, _i64, _i64, _i64, _i64, _i, _i, _i, _i, _i64, _vp]),
     "sp_gemm_tn_splits": (_i, [_i, _i, _i, _i]),
     "sp_sum_slabs_f32": (_i, [_vp, _i, _i64, _i64, _vp, _i, _vp, _vp]),
+    "sp_linear_pack": (_i, [_vp, _i, _i, _i, _vp, _i, _vp, _vp, _vp]),
     "sp_layernorm_fwd": (_i, [_vp, _vp, _vp, _i64, _i, _f, _i, _vp, _i64, _vp, _vp, _vp]),
     "sp_layernorm_bwd": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _i64, _i, _i, _vp, _vp, _vp, _vp]),
 }

@@ -254,6 +254,35 @@ __global__ void sum_slabs_kernel(const float* __restrict__ P, int S, int64_t n4,
     }
 }
 
+// Linear-layer weight [V][n] f32 -> the 16-bit operands of its three products in ONE launch: out_w [Vp][n]
+// (rows V..Vp zero: the logits GEMM works on whole 256-column tiles) and / or out_t [n][Vp] = scale * W^T
+// (the K-contiguous B operand of the data gradient, with the incoming loss gradient folded in).  64 x 64 tiles
+// through LDS: reads and both writes are row-contiguous.
+template <typename T>
+__global__ __launch_bounds__(256) void linear_pack_kernel(const float* __restrict__ w, int V, int n, int Vp,
+                                                         const float* __restrict__ scale, T* __restrict__ out_w,
+                                                         T* __restrict__ out_t) {
+    __shared__ float tile[64][65];
+    const int v0 = blockIdx.y * 64, c0 = blockIdx.x * 64;
+    const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+    const float sc = scale ? *scale : 1.f;
+#pragma unroll 4
+    for (int r = ty; r < 64; r += 4) {
+        const int v = v0 + r, c = c0 + tx;
+        const float x = (v < V && c < n) ? w[(int64_t)v * n + c] : 0.f;
+        tile[r][tx] = x;
+        if (out_w && v < Vp && c < n) Elem<T>::st(out_w + (int64_t)v * n + c, x);
+    }
+    __syncthreads();
+    if (out_t) {
+#pragma unroll 4
+        for (int r = ty; r < 64; r += 4) {
+            const int c = c0 + r, v = v0 + tx;
+            if (c < n && v < Vp) Elem<T>::st(out_t + (int64_t)c * Vp + v, tile[tx][r] * sc);
+        }
+    }
+}
+
 }  // namespace sp
 
 extern "C" int sp_sum_slabs_f32(const float* partials, int S, int64_t n, int64_t slab_stride, float* out,
@@ -269,4 +298,22 @@ extern "C" int sp_sum_slabs_f32(const float* partials, int S, int64_t n, int64_t
     hipLaunchKernelGGL(sum_slabs_kernel, dim3(blocks), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), partials, S, n4,
                        slab_stride, out, accumulate, scale_dev);
     return check_launch("sum_slabs_kernel");
+}
+
+extern "C" int sp_linear_pack(const float* weight, int V, int n, int Vp, const float* scale_dev, int dtype, void* out_w,
+                              void* out_t, void* stream) {
+    using namespace sp;
+    SP_CHECK_ARG(V >= 1 && n >= 1 && Vp >= V, "sp_linear_pack: bad shape V=%d n=%d Vp=%d", V, n, Vp);
+    SP_CHECK_ARG(dtype == SP_BF16 || dtype == SP_F16, "sp_linear_pack: dtype %d (bf16 or f16)", dtype);
+    SP_CHECK_ARG(weight && (out_w || out_t), "sp_linear_pack: null pointer");
+    const dim3 grid((n + 63) / 64, (Vp + 63) / 64);
+    SP_CHECK_ARG(grid.y <= 65535, "sp_linear_pack: Vp=%d exceeds the grid limit", Vp);
+    hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+    if (dtype == SP_BF16)
+        hipLaunchKernelGGL((linear_pack_kernel<__hip_bfloat16>), grid, dim3(256), 0, s, weight, V, n, Vp, scale_dev,
+                           (__hip_bfloat16*)out_w, (__hip_bfloat16*)out_t);
+    else
+        hipLaunchKernelGGL((linear_pack_kernel<__half>), grid, dim3(256), 0, s, weight, V, n, Vp, scale_dev, (__half*)out_w,
+                           (__half*)out_t);
+    return check_launch("linear_pack_kernel");
 }

@@ -586,6 +586,22 @@ def _splitk_dw(xn, gU2):
 _VPAD = 256     # the fast GEMM kernels work on whole 256-column tiles
 
 
+def _linear_pack(weight, Vp, dtype, scale=None, transposed=False):
+    """sp_linear_pack: the f32 weight [V, n] as a 16-bit [Vp, n] (rows V.. zero) or, transposed=True, as
+    scale * W^T [n, Vp] -- one launch either way."""
+    V, n = weight.shape
+    w = weight.detach()
+    if w.dtype != torch.float32 or not w.is_contiguous():
+        w = w.float().contiguous()
+    out = torch.empty((n, Vp) if transposed else (Vp, n), dtype=dtype, device=w.device)
+    if scale is not None:
+        scale = scale.detach().reshape(-1)[:1].float().contiguous()
+    with torch.cuda.device(w.device):
+        check(lib().sp_linear_pack(ptr(w), V, n, Vp, ptr(scale), _lib.dtype_code(out), None if transposed else ptr(out),
+                                   ptr(out) if transposed else None, stream_ptr()), "sp_linear_pack")
+    return out
+
+
 def _classifier_pack(weight, dtype, M):
     """The classifier weight [V, n] in the activation dtype, rows zero-padded to whole 256-column tiles when
     the problem is big enough for the persistent kernels (logits and their gradient are then [M, Vp] buffers of
@@ -594,9 +610,7 @@ def _classifier_pack(weight, dtype, M):
     if dtype not in (torch.bfloat16, torch.float16) or M < 4096 or n % 256 or V % _VPAD == 0:
         return weight.detach().to(dtype), V
     Vp = (V + _VPAD - 1) // _VPAD * _VPAD
-    wb = torch.zeros((Vp, n), dtype=dtype, device=weight.device)
-    wb[:V].copy_(weight.detach())
-    return wb, Vp
+    return _linear_pack(weight, Vp, dtype), Vp
 
 
 def _classifier_logits(x2d, weight):
@@ -606,10 +620,14 @@ def _classifier_logits(x2d, weight):
     return gemm(x2d, wb, out_dtype=torch.float32)[:, :weight.shape[0]], wb
 
 
-def _classifier_dx(gb, wb, scale=None):
-    """gb [M, Vp] (pad columns zero) times wb [Vp, n]; with a padded weight as an NT product on wb^T."""
+def _classifier_dx(gb, wb, scale=None, weight=None):
+    """gb [M, Vp] (pad columns zero) times wb [Vp, n]; with a padded weight as an NT product on scale * W^T, which
+    sp_linear_pack takes straight from the f32 parameter (`weight`, unchanged since the forward)."""
+    fast = wb.shape[0] % _VPAD == 0 and gb.shape[0] >= 4096 and wb.dtype in (torch.bfloat16, torch.float16)
+    if fast and weight is not None:
+        return gemm(gb, _linear_pack(weight, wb.shape[0], wb.dtype, scale, transposed=True))
     w = wb if scale is None else (wb.float() * scale).to(wb.dtype)
-    if wb.shape[0] % _VPAD == 0 and gb.shape[0] >= 4096 and wb.dtype in (torch.bfloat16, torch.float16):
+    if fast:
         return gemm(gb, w.t().contiguous())
     return gemm(gb, w.t())
 
@@ -641,13 +659,13 @@ class _ClassifierFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x2d, weight):
         out, wb = _classifier_logits(x2d, weight)
-        ctx.save_for_backward(x2d, wb)
+        ctx.save_for_backward(x2d, wb, weight)
         ctx.weight = weight
         return out
 
     @staticmethod
     def backward(ctx, g):
-        x2d, wb = ctx.saved_tensors
+        x2d, wb, w32 = ctx.saved_tensors
         V, Vp = ctx.weight.shape[0], wb.shape[0]
         if Vp != V:         # pad columns zero: they meet the padded weight's zero rows
             gb = torch.empty((g.shape[0], Vp), dtype=x2d.dtype, device=g.device)
@@ -655,7 +673,47 @@ class _ClassifierFn(torch.autograd.Function):
             gb[:, :V].copy_(g)
         else:
             gb = g.to(x2d.dtype).contiguous()
-        return _classifier_dx(gb, wb), _classifier_dw(gb, x2d, ctx.weight)
+        return _classifier_dx(gb, wb, None, w32), _classifier_dw(gb, x2d, ctx.weight)
+
+
+_len_cache = {}
+_gbuf_pool = {}      # key -> [buffer, in_use]
+
+
+def _full_lengths(B, T, device):
+    """int32 [B] filled with T, kept per shape (one fill kernel per step otherwise)."""
+    key = (B, T, str(device))
+    t = _len_cache.get(key)
+    if t is None:
+        if len(_len_cache) > 64:
+            _len_cache.clear()
+        t = _len_cache[key] = torch.full((B,), T, dtype=torch.int32, device=device)
+    return t
+
+
+def _grad_buffer(M, V, Vp, dtype, device):
+    """[M, Vp] buffer for the CTC gradient whose pad columns V.. are zero.  The CTC kernel writes columns < V
+    only, so a buffer that went through one step keeps its zero pad: one buffer per shape is handed out again
+    once its backward has released it (a second forward before that gets a fresh one)."""
+    if Vp == V:
+        return torch.empty((M, Vp), dtype=dtype, device=device), None
+    key = (M, V, Vp, dtype, str(device))
+    ent = _gbuf_pool.get(key)
+    if ent is not None and not ent[1]:
+        ent[1] = True
+        return ent[0], key
+    buf = torch.empty((M, Vp), dtype=dtype, device=device)
+    buf[:, V:].zero_()
+    if len(_gbuf_pool) > 8:
+        _gbuf_pool.clear()
+    _gbuf_pool[key] = [buf, True]
+    return buf, key
+
+
+def _release_grad_buffer(key, buf):
+    ent = _gbuf_pool.get(key) if key is not None else None
+    if ent is not None and ent[0].data_ptr() == buf.data_ptr():
+        ent[1] = False
 
 
 class _HeadCTCFn(torch.autograd.Function):
@@ -673,22 +731,23 @@ class _HeadCTCFn(torch.autograd.Function):
         logits, wb = _classifier_logits(x2d, weight)            # [T*B, V] view, row pitch Vp
         Vp = wb.shape[0]
         ctx.weight = weight
-        il = torch.full((B,), T, dtype=torch.int32, device=x_tm.device)        # train.py:72-74: all T' frames
-        gbuf = torch.empty((T * B, Vp), dtype=x2d.dtype, device=x2d.device)    # the gradient leaves the kernel in
-        if Vp != V:                                                            # the GEMMs' dtype, pad columns zero
-            gbuf[:, V:].zero_()
+        il = _full_lengths(B, T, x_tm.device)                                  # train.py:72-74: all T' frames
+        gbuf, ctx.gkey = _grad_buffer(T * B, V, Vp, x2d.dtype, x2d.device)     # the gradient leaves the kernel in
+                                                                               # the GEMMs' dtype, pad columns zero
         loss, _, _ = ctc_fwd_bwd(logits.as_strided((T, B, V), (B * Vp, Vp, 1)), labels, il, label_lengths, blank,
                                  max_label_len, True, 1.0, True, x2d.dtype,
                                  grad_out=gbuf.as_strided((T, B, V), (B * Vp, Vp, 1)))
-        ctx.save_for_backward(x2d, wb, gbuf)
+        ctx.save_for_backward(x2d, wb, gbuf, weight)
         ctx.shape = (T, B, n)
         return loss[0]
 
     @staticmethod
     def backward(ctx, g):
-        x2d, wb, gb = ctx.saved_tensors
-        return (_classifier_dx(gb, wb, g).view(ctx.shape), _classifier_dw(gb, x2d, ctx.weight, g),
-                None, None, None, None)
+        x2d, wb, gb, w32 = ctx.saved_tensors
+        gx = _classifier_dx(gb, wb, g, w32).view(ctx.shape)
+        gw = _classifier_dw(gb, x2d, ctx.weight, g)
+        _release_grad_buffer(ctx.gkey, gb)
+        return gx, gw, None, None, None, None
 
 
 def classifier_ctc_loss(x_tm, weight, labels, label_lengths, blank=0, max_label_len=None):

@@ -59,6 +59,10 @@ def test_version_and_error_string():
     assert h.sp_gemm_tn_splits(1024, 3072, 24032, 0) == 8 and h.sp_gemm_tn_splits(100, 100, 100, 2) == 1
     rc = h.sp_sum_slabs_f32(16, 2, 6, 8, 16, 0, None, None)
     assert rc == -1 and b"multiples of 4" in h.sp_last_error()
+    rc = h.sp_linear_pack(16, 1000, 1024, 999, None, 2, 16, None, None)
+    assert rc == -1 and b"Vp" in h.sp_last_error()                       # the padded row count cannot be below V
+    rc = h.sp_linear_pack(16, 1000, 1024, 1024, None, 0, 16, None, None)
+    assert rc == -1 and b"dtype" in h.sp_last_error()                    # 16-bit outputs only
     rc = h.sp_sru_pack_wt(16, 96, 64, 3, 1, 2, 16, 96, None, None)
     assert rc == -1 and b"n_in" in h.sp_last_error()                     # bf16 tiles are 64 rows
     rc = h.sp_sru_pack_wt(16, 128, 64, 3, 1, 2, 16, 100, None, None)

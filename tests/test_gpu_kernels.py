@@ -1046,3 +1046,27 @@ def test_beam_decoder_end_to_end(cuda, tmp_path):
     assert dec0.decode(amb.to(cuda)) == "tha cat" and dec1.decode(amb.to(cuda)) == "the cat"
     beams = dec1.decode_beams(amb.to(cuda), n_best=3)
     assert beams[0][0] == "the cat" and beams[0][2] >= beams[1][2]
+
+
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
+def test_linear_pack(cuda, dtype):
+    """sp_linear_pack: padded 16-bit weight and scaled transpose against torch, ragged V and n."""
+    from speech_amd import ops
+    g = torch.Generator().manual_seed(5)
+    for V, n, Vp in [(1000, 1024, 1024), (29, 1024, 256), (70, 96, 70), (129, 200, 192)]:
+        w = torch.randn(V, n, generator=g).to(cuda)
+        wb = ops._linear_pack(w, Vp, dtype)
+        assert wb.shape == (Vp, n)
+        assert torch.equal(wb[:V], w.to(dtype))
+        assert float(wb[V:].float().abs().max()) == 0.0 if Vp > V else True
+        sc = torch.tensor(0.37, device=cuda)
+        wt = ops._linear_pack(w, Vp, dtype, sc, transposed=True)
+        assert wt.shape == (n, Vp)
+        # scale and rounding are one instruction on the device (single rounding): torch's product is rounded to
+        # f32 first, so an occasional element differs by one unit in the last place
+        ref = (w * sc).t()
+        ulp = 2.0 ** (-7 if dtype == torch.bfloat16 else -10)
+        assert float(((wt[:, :V].float() - ref).abs() / (ref.abs() + 1e-4)).max()) <= ulp
+        assert float((wt[:, :V] != ref.to(dtype)).float().mean()) < 1e-2
+        assert float(wt[:, V:].float().abs().max()) == 0.0 if Vp > V else True
+        assert torch.equal(ops._linear_pack(w, Vp, dtype, None, transposed=True)[:, :V], w.to(dtype).t())

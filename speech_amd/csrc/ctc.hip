@@ -14,8 +14,8 @@
 //                  (new = (a[s] + a[s-1] + skip*a[s-2]) * y: DPP move, add, fma, mul -- no exp/log
 //                  on the chain); the emission y = 2^(log2-prob) is built off the chain from an f32
 //                  v_exp_f32 of the fraction and an f64 ldexp of the integer part, so rows as
-//                  improbable as 2^-1000 stay exact; every 4th frame the wave maximum's exponent
-//                  (measured 3 frames earlier, off the chain) is folded into that ldexp and added
+//                  improbable as 2^-1000 stay exact; every 8th frame the wave maximum's exponent
+//                  (measured 7 frames earlier, off the chain) is folded into that ldexp and added
 //                  to the row's integer scale E_t.  Each thread owns NS consecutive lattice states;
 //                  neighbours come from the adjacent lane by DPP wave shift, and only the
 //                  wave-boundary state crosses LDS (one barrier per frame, none for a single-wave
@@ -28,7 +28,7 @@
 //
 // Workspace: lse2[B*T] | rows[B][T][RW] (f32), then f64 alpha[B][T][SP] | beta_rev[B][T][SP] | nll2[B]
 // | aux.  True alpha_t(s) = alpha[b][t][s] * 2^E_t.  SP = 2*Lmax+1 rounded up to 8 > S: the multi-wave
-// kernel keeps E_t in slot SP-1 of the row; the single-wave kernel writes E once per 4-frame block
+// kernel keeps E_t in slot SP-1 of the row; the single-wave kernel writes E once per 8-frame block
 // into its aux block (and parks the stores of lanes beyond SP on a dummy row there).
 //
 // Precision: log alpha/beta reach thousands of log2 units, where one f32 ulp is ~2e-4: a plain f32
@@ -57,7 +57,12 @@ constexpr float kLog2e = 1.4426950408889634f;
 constexpr int kMaxV = 4000;  // K3 keeps 4 x V floats of per-class sums in LDS (<= 64 KB)
 constexpr int kMaxL = 1023;
 constexpr int kPF = 8;  // float4 prefetch registers per thread in K2
-constexpr int kRescale = 4;  // K2: frames per rescale block (the exponent measured at its start is applied in its last frame)
+constexpr int kRescale = 8;  // K2: frames per rescale block (the exponent measured at its start is applied in its last frame)
+// The rescale parks the row maximum at 2^kTopBits, not at 1: what the recursion needs is room BELOW the maximum (states
+// that carry the posterior can sit hundreds of binary orders under it, and a block's emissions shrink everything for up
+// to 2 * kRescale frames before the next correction lands), while above it a row can only grow 3x per frame
+// (3^16 = 2^26).  f64 then offers ~1900 binary orders below the maximum instead of 1022.
+constexpr int kTopBits = 900;
 
 struct CtcDims {
     int T, B, V, Lmax;
@@ -375,7 +380,7 @@ __global__ __launch_bounds__(64 * W) void ctc_lattice_kernel(
                 if (W > 1) {
                     if (lane == 0) s_emax[(i / kRescale) & 1][wave] = e;   // read after >= 1 barrier
                 } else {
-                    dp = e ? e - 1023 : 0;
+                    dp = e ? e - (1023 + kTopBits) : 0;
                 }
             }
             double y[kRescale][NS];
@@ -407,7 +412,7 @@ __global__ __launch_bounds__(64 * W) void ctc_lattice_kernel(
                         int e = 0;
 #pragma unroll
                         for (int w = 0; w < W; ++w) e = max(e, s_emax[(i / kRescale) & 1][w]);
-                        dp = e ? e - 1023 : 0;
+                        dp = e ? e - (1023 + kTopBits) : 0;
 #pragma unroll
                         for (int j = 0; j < NS; ++j) y[q][j] = ldexp(y[q][j], -dp);
                     }
@@ -646,7 +651,7 @@ __global__ __launch_bounds__(192) void ctc_lattice1_kernel(
 #pragma unroll
             for (int j = 1; j < NS; ++j) m = fmax(m, a[j]);
             const int e = wave_max_i((__double2hiint(m) >> 20) & 0x7FF);
-            const int dp = e ? e - 1023 : 0;
+            const int dp = e ? e - (1023 + kTopBits) : 0;
             double y[kRescale][NS];
 #pragma unroll
             for (int q = 0; q < kRescale; ++q) {
@@ -666,7 +671,7 @@ __global__ __launch_bounds__(192) void ctc_lattice1_kernel(
                 spill();
             }
             E += dp;
-            ecum[i / kRescale] = (double)E;   // the scale of frame i+3 and of the next block's first three
+            ecum[i / kRescale] = (double)E;   // the scale of the block's last frame and of the next block's first seven
             i += kRescale;
         }
         for (; k0 < nsteps; ++k0, ++i) {   // tail frames of the sequence: no rescale

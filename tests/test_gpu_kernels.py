@@ -1070,3 +1070,25 @@ def test_linear_pack(cuda, dtype):
         assert float((wt[:, :V] != ref.to(dtype)).float().mean()) < 1e-2
         assert float(wt[:, V:].float().abs().max()) == 0.0 if Vp > V else True
         assert torch.equal(ops._linear_pack(w, Vp, dtype, None, transposed=True)[:, :V], w.to(dtype).t())
+
+
+def test_ctc_sharp_logits_range(cuda):
+    """Logits scaled until the mean loss is ~13, ~30 and ~45 bits PER FRAME (random labels against sharp random
+    scores: every frame shrinks the lattice by that much): the scaled-probability recursion with its 8-frame
+    rescale blocks must still agree with torch's float64 log-space CTC, loss and gradient."""
+    from speech_amd import ops
+    B, T, V, L = 4, 300, 1000, 40
+    for scale in (3.0, 8.0, 12.0):
+        g = torch.Generator().manual_seed(3)
+        logits = torch.randn(T, B, V, generator=g) * scale
+        labels = torch.randint(1, V, (B, L), generator=g)
+        ll = torch.tensor([40, 33, 20, 40], dtype=torch.int32)
+        il = torch.full((B,), T, dtype=torch.int32)
+        z = logits.double().requires_grad_(True)
+        ref = torch.nn.functional.ctc_loss(torch.log_softmax(z, -1), labels, il.long(), ll.long(), blank=0, reduction="none")
+        (ref / ll.double().clamp(min=1)).mean().backward()
+        _, nll, grad = ops.ctc_fwd_bwd(logits.to(cuda).transpose(0, 1), labels.to(cuda), il.to(cuda), ll.to(cuda), max_label_len=L)
+        assert float(((nll.cpu().double() - ref.detach()).abs() / ref.detach()).max()) <= 1e-6, scale
+        gr = z.grad.transpose(0, 1)
+        assert bool(torch.isfinite(grad).all())
+        assert float((grad.cpu().double() - gr).abs().max()) <= 1e-4 * float(gr.abs().max()), scale

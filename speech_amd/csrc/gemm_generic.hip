@@ -266,16 +266,21 @@ __global__ __launch_bounds__(256) void linear_pack_kernel(const float* __restric
     const int v0 = blockIdx.y * 64, c0 = blockIdx.x * 64;
     const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
     const float sc = scale ? *scale : 1.f;
-#pragma unroll 4
-    for (int r = ty; r < 64; r += 4) {
-        const int v = v0 + r, c = c0 + tx;
-        const float x = (v < V && c < n) ? w[(int64_t)v * n + c] : 0.f;
-        tile[r][tx] = x;
-        if (out_w && v < Vp && c < n) Elem<T>::st(out_w + (int64_t)v * n + c, x);
+    float x[16];
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {      // all sixteen loads of the thread in flight at once
+        const int v = v0 + ty + 4 * i, c = c0 + tx;
+        x[i] = (v < V && c < n) ? w[(int64_t)v * n + c] : 0.f;
+    }
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+        const int r = ty + 4 * i, v = v0 + r, c = c0 + tx;
+        tile[r][tx] = x[i];
+        if (out_w && v < Vp && c < n) Elem<T>::st(out_w + (int64_t)v * n + c, x[i]);
     }
     __syncthreads();
     if (out_t) {
-#pragma unroll 4
+#pragma unroll
         for (int r = ty; r < 64; r += 4) {
             const int c = c0 + r, v = v0 + tx;
             if (c < n && v < Vp) Elem<T>::st(out_t + (int64_t)c * Vp + v, tile[tx][r] * sc);

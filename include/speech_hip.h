@@ -84,6 +84,11 @@ int sp_melspec_fwd(const void* wav, const int64_t* wav_offsets, int B, int T_max
  * grad_scale * d loss / d logits, of grad_dtype SP_F32 or SP_BF16 (same strides in elements; bf16
  * when the consumer is a bf16 GEMM: its rounding happens in the store); frames t >=
  * input_lengths[b] get 0.
+ * Range: the lattice runs on scaled f64 probabilities, not in log space.  It agrees with torch's float64 CTC to
+ * 1e-7 on scores as sharp as a mean loss of 45 bits (31 nats) per frame (tests/test_gpu_kernels.py
+ * test_ctc_sharp_logits_range; a randomly initialised model sits at log2 V, a trained one below 3); scores that are
+ * sharper AND wrong for tens of frames on end can push the states that carry the posterior out of f64's range below
+ * the row maximum: the result then degrades (percent-level error, finally +inf) instead of staying exact.
  * --------------------------------------------------------------------------------------- */
 size_t sp_ctc_workspace_bytes(int T, int B, int V, int max_label_len);
 int sp_ctc_fwd_bwd(const float* logits, int64_t stride_t, int64_t stride_b, const int64_t* labels,

@@ -177,7 +177,7 @@ __device__ __forceinline__ void transform_frames(const S* __restrict__ x, int N,
     // The wave's 1520 samples, [t0*160 - 200, (t0+7)*160 + 200), are read ONCE, coalesced, into LDS; the
     // 2.5-fold frame overlap and the stride-50 gathers of the 8-point transforms are served from there.
     // Waves at an utterance's ends (reflection, frames past the end) take the element-wise path.
-    // The lane's window taps and twiddles of phases 1 and 3 are requested first (L2 hits): the wait for the
+    // (int16 PCM: the same, 8 bytes per lane and round.)  The lane's window taps and twiddles of phases 1 and 3 are requested first (L2 hits): the wait for the
     // samples covers them.
     const int fh = lane >= 25 ? 1 : 0;
     const int n2 = min(lane - 25 * fh, 24);
@@ -199,6 +199,35 @@ __device__ __forceinline__ void transform_frames(const S* __restrict__ x, int N,
 #pragma unroll
         for (int i = 0; i < 6; ++i)
             if (lane + 64 * i < kStage / 4) reinterpret_cast<lds_f4*>(L)[lane + 64 * i] = v[i];
+    } else if (sizeof(S) == 2 && s0 >= 0 && s0 + kStage + 2 <= N) {
+        // int16 PCM, interior wave: 4 samples per lane and round from whole dwords.  The first sample may sit in
+        // the upper half of its dword (utterance offsets are in samples): sh = 0 / 1 halfwords, three dwords cover
+        // the lane's four samples either way and v_alignbit shifts them into place.
+        const uintptr_t a0 = reinterpret_cast<uintptr_t>(x + s0);
+        const int sh = (int)(a0 >> 1) & 1;
+        typedef uint32_t __attribute__((aligned(4))) u32a;
+        typedef __attribute__((ext_vector_type(2))) uint32_t u32x2;
+        typedef u32x2 __attribute__((aligned(4))) u32x2a;
+        const u32a* q = reinterpret_cast<const u32a*>(a0 - 2 * sh);
+        u32x2 d01[6];
+        uint32_t d2[6];
+#pragma unroll
+        for (int i = 0; i < 6; ++i) {
+            const int g = min(lane + 64 * i, kStage / 4 - 1);
+            d01[i] = *reinterpret_cast<const u32x2a*>(q + 2 * g);
+            d2[i] = q[2 * g + 2];
+        }
+#pragma unroll
+        for (int i = 0; i < 6; ++i) {
+            const uint32_t w0 = __builtin_amdgcn_alignbit(d01[i].y, d01[i].x, 16 * sh);
+            const uint32_t w1 = __builtin_amdgcn_alignbit(d2[i], d01[i].y, 16 * sh);
+            f32x4 v;
+            v.x = (float)(int16_t)(w0 & 0xffff) * (1.f / 32768.f);
+            v.y = (float)((int32_t)w0 >> 16) * (1.f / 32768.f);
+            v.z = (float)(int16_t)(w1 & 0xffff) * (1.f / 32768.f);
+            v.w = (float)((int32_t)w1 >> 16) * (1.f / 32768.f);
+            if (lane + 64 * i < kStage / 4) reinterpret_cast<lds_f4*>(L)[lane + 64 * i] = v;
+        }
     } else {
 #pragma unroll 4
         for (int i = 0; i < (kStage + 63) / 64; ++i) {
@@ -313,10 +342,10 @@ __global__ __launch_bounds__(64 * kWPB, 3) void melspec_kernel(
         mf0 = masks[b * 4 + 0]; mfw = masks[b * 4 + 1];
         mt0 = masks[b * 4 + 2]; mtw = masks[b * 4 + 3];
     }
-    // this wave's share of the projection: slots [slot_beg, slot_end); its first group of filterbank images is
+    // this wave's share of the projection: plan->share_groups[par] groups from slot slot_beg on; its first group of filterbank images is
     // requested here, three phases ahead of its use
     const int par = wave & 1;
-    const int slot_beg = par ? plan->split : 0, slot_end = par ? kTiles : plan->split;
+    const int slot_beg = par ? plan->split : 0;
     const float* a_ptr = plan->fbt[plan->slot_blk0[slot_beg]] + lane;
     float a_p[kGroup], a_q[kGroup];   // images of the group being multiplied and of the one after it
 #pragma unroll

@@ -13,19 +13,26 @@ from . import ctc as octc
 from . import sru as osru
 
 
-def forward(sd, x, n_rnn_layers, rnn_dim, training=False, masks=None, bn_stats=None):
-    """sd: state_dict-like mapping name -> tensor (float32/64, CPU).  x [B,1,F,T] -> logits [B,T',V]."""
+def forward(sd, x, n_rnn_layers, rnn_dim, training=False, masks=None, bn_stats=None, bf16_conv=False):
+    """sd: state_dict-like mapping name -> tensor (float32/64, CPU).  x [B,1,F,T] -> logits [B,T',V].
+    bf16_conv: round where the HIP conv stack rounds -- stem output, the 3x5 convolutions' weights, inputs and
+    outputs, every block's output -- so that a comparison with it is left with accumulation order only (the
+    reference itself runs these layers under fp16 autocast, train.py:66)."""
+    def q(t):
+        return t.bfloat16().to(t.dtype) if bf16_conv else t
+
     def bn(y, prefix):
         return F.batch_norm(y, sd[prefix + ".running_mean"].clone(), sd[prefix + ".running_var"].clone(),
                             sd[prefix + ".weight"], sd[prefix + ".bias"], training=training,
                             momentum=0.1, eps=1e-5)
-    y = F.conv2d(x, sd["cnn.weight"], sd["cnn.bias"], stride=2, padding=1)
+    y = q(F.conv2d(x, sd["cnn.weight"], sd["cnn.bias"], stride=2, padding=1))
     for i in range(3):
         p = f"resnet_layers.{i}"
         r = y
-        y = F.relu(bn(F.conv2d(y, sd[p + ".conv1.weight"], sd[p + ".conv1.bias"], padding=(1, 2)), p + ".bn1"))
-        y = bn(F.conv2d(y, sd[p + ".conv2.weight"], sd[p + ".conv2.bias"], padding=(1, 2)), p + ".bn2")
-        y = F.relu(y + r)
+        y = q(F.conv2d(y, q(sd[p + ".conv1.weight"]), sd[p + ".conv1.bias"], padding=(1, 2)))
+        y = q(F.relu(bn(y, p + ".bn1")))
+        y = q(F.conv2d(y, q(sd[p + ".conv2.weight"]), sd[p + ".conv2.bias"], padding=(1, 2)))
+        y = q(F.relu(bn(y, p + ".bn2") + r))
     B, C, Fq, T = y.shape
     y = y.reshape(B, C * Fq, T).permute(2, 0, 1).contiguous()          # net.py:82-83
     layers = []

@@ -46,7 +46,9 @@ def test_state_dict_layout_matches_reference_names(cuda):
 @pytest.mark.parametrize("train", [False, True])
 def test_model_forward_matches_cpu_oracle(cuda, train):
     """SRModel on the HIP kernels (f32 SRU stack, bf16 conv stack) vs oracle.net on the CPU with the
-    same state_dict.  Tolerance: 5 % of the logit range -- the conv stack keeps bf16 activations."""
+    same state_dict.  Against the plain f32 oracle: 2.5 % of the logit range (measured 0.5 % eval / 1.2 % train: the
+    conv stack keeps bf16 activations); against the oracle that rounds to bf16 where the conv stack does: 1 %
+    (measured 0.15 % / 0.56 %: accumulation order and the batch statistics of unrounded sums)."""
     m = _small_model(cuda)
     m.train(train)
     g = torch.Generator().manual_seed(1)
@@ -55,8 +57,13 @@ def test_model_forward_matches_cpu_oracle(cuda, train):
     with torch.no_grad():
         out = m(spec.to(cuda)).float().cpu()
         ref = onet.forward(sd, spec, 2, 64, training=train)
+        ref_q = onet.forward(sd, spec, 2, 64, training=train, bf16_conv=True)
     assert out.shape == ref.shape == (2, 61, 29)
-    assert float((out - ref).abs().max()) <= 5e-2 * float(ref.abs().max())
+    assert float((out - ref).abs().max()) <= 2.5e-2 * float(ref.abs().max())
+    # against the oracle that rounds where the conv stack rounds, what is left is accumulation order
+    print("encoder forward: max error vs f32 oracle %.4f, vs bf16-rounding oracle %.4f of the logit range" %
+          (float((out - ref).abs().max()) / float(ref.abs().max()), float((out - ref_q).abs().max()) / float(ref_q.abs().max())))
+    assert float((out - ref_q).abs().max()) <= 1e-2 * float(ref_q.abs().max())
 
 
 def test_model_gradients_match_cpu_oracle(cuda):

@@ -46,13 +46,13 @@ def forward(sd, x, n_rnn_layers, rnn_dim, training=False, masks=None, bn_stats=N
     return y @ sd["classifier.1.weight"].t()
 
 
-def loss_and_grads(sd, x, labels, label_lengths, n_rnn_layers, rnn_dim, training=True, masks=None):
+def loss_and_grads(sd, x, labels, label_lengths, n_rnn_layers, rnn_dim, training=True, masks=None, bf16_conv=False):
     """train.py:66-79 on the CPU: forward, log_softmax, CTC (input_lengths all = T'), backward.
     Returns (loss, {name: grad}) for the floating-point parameters."""
     names = [k for k, v in sd.items() if v.is_floating_point() and "running_" not in k and k != "scale_x"
              and not k.endswith("scale_x")]
     leaf = {k: (sd[k].detach().clone().requires_grad_(True) if k in names else sd[k]) for k in sd}
-    logits = forward(leaf, x, n_rnn_layers, rnn_dim, training=training, masks=masks)
+    logits = forward(leaf, x, n_rnn_layers, rnn_dim, training=training, masks=masks, bf16_conv=bf16_conv)
     lp = F.log_softmax(logits, dim=2).transpose(0, 1)
     il = torch.full((x.shape[0],), lp.shape[0], dtype=torch.int32)
     loss = F.ctc_loss(lp, labels, il, label_lengths.to(torch.int32), blank=0)

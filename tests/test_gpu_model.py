@@ -66,6 +66,9 @@ def test_model_forward_matches_cpu_oracle(cuda, train):
     assert float((out - ref_q).abs().max()) <= 1e-2 * float(ref_q.abs().max())
 
 
+LOSS_TOL, GRAD_TOL = 5e-3, 2e-2   # measured: loss 4e-4, gradients behind the conv stack 3e-3 .. 5e-3
+
+
 def test_model_gradients_match_cpu_oracle(cuda):
     from speech_amd import ops
     m = _small_model(cuda, layers=2)
@@ -80,12 +83,30 @@ def test_model_gradients_match_cpu_oracle(cuda):
     loss = ops.ctc_loss(logits, labels.to(cuda), il, ll.to(cuda))
     loss.backward()
     ref_loss, ref_grads, _ = onet.loss_and_grads(sd, spec, labels, ll, 2, 64, training=True)
-    assert float(loss) == pytest.approx(float(ref_loss), rel=3e-2)
+    q_loss, q_grads, _ = onet.loss_and_grads(sd, spec, labels, ll, 2, 64, training=True, bf16_conv=True)
+    print("loss rel err: f32 oracle %.4f, bf16-rounding oracle %.4f" % (abs(float(loss) / float(ref_loss) - 1), abs(float(loss) / float(q_loss) - 1)))
+    assert float(loss) == pytest.approx(float(ref_loss), rel=LOSS_TOL)
     named = dict(m.named_parameters())
+    # everything behind the conv stack: 2 % (measured 0.3-0.5 % against the f32 oracle, 0.1 % against the one that
+    # rounds like the conv stack).  The conv stack's own parameters: their gradients pass through bf16 activation
+    # gradients and batch-statistics BatchNorm backward, which subtracts the gradient's mean and its projection on
+    # the normalised activation -- a cancellation that amplifies the 2^-9 rounding of the stored tensors:
+    # measured 6-12 % of the largest entry against the f32 oracle, 4 % against the rounding oracle.
     for k in ["classifier.1.weight", "sru_layers.rnn_lst.1.weight", "sru_layers.rnn_lst.1.weight_c",
               "sru_layers.rnn_lst.0.weight", "sru_layers.rnn_lst.0.layer_norm.weight", "sru_layers.rnn_lst.0.bias"]:
-        a, b = named[k].grad.cpu(), ref_grads[k]
-        assert float((a - b).abs().max()) <= 8e-2 * float(b.abs().max()) + 1e-7, k
+        a, b, c = named[k].grad.cpu(), ref_grads[k], q_grads[k]
+        print("%-45s f32 oracle %.4f  bf16-rounding oracle %.4f" % (k, float((a - b).abs().max()) / float(b.abs().max()),
+                                                                     float((a - c).abs().max()) / float(c.abs().max())))
+        assert float((a - b).abs().max()) <= GRAD_TOL * float(b.abs().max()) + 1e-7, k
+    for k in ["resnet_layers.2.conv2.weight", "resnet_layers.0.conv1.weight", "resnet_layers.1.bn1.weight", "cnn.weight"]:
+        a, b, c = named[k].grad.cpu(), ref_grads[k], q_grads[k]
+        print("%-45s f32 oracle %.4f  bf16-rounding oracle %.4f" % (k, float((a - b).abs().max()) / float(b.abs().max()),
+                                                                     float((a - c).abs().max()) / float(c.abs().max())))
+        assert float((a - b).abs().max()) <= 2e-1 * float(b.abs().max()) + 1e-7, k
+        assert float((a - c).abs().max()) <= 1e-1 * float(c.abs().max()) + 1e-7, k
+        cos = float((a.flatten() * c.flatten()).sum() / (a.norm() * c.norm()))
+        print("    cosine with the rounding oracle %.5f" % cos)
+        assert cos >= 0.995, k
 
 
 def test_adam_clips_the_mean_gradient_under_data_parallel(cuda):

@@ -263,7 +263,50 @@ def cpu_baseline(args, V):
     dt = time.time() - t0
     return {"value": Bs * args.seconds / dt, "unit": "audio-sec/sec", "cores": cores, "kind": "port",
             "sample": f"1 training step on {Bs} x {args.seconds:g} s utterances (fp32, CPU oracle: torch.stft mel, "
-                      f"torch conv/BN/GEMM, python-loop SRU, torch CTC, torch Adam), {dt:.1f} s wall"}
+                      f"torch conv/BN/GEMM, python-loop SRU, torch CTC, torch Adam), {dt:.1f} s wall",
+            "parts": cpu_parts(args, V, cores)}
+
+
+def cpu_parts(args, V, cores):
+    """the north-star stages on the host alone, as the reference runs them -- (a) the frontend one
+    utterance at a time like collate_fn (oracle.mel = torch.stft + filterbank matmul), (b) F.ctc_loss forward +
+    backward on [T', B, V] log-probs, (c) argmax + the Python collapse loop of decoder.py.  Bounded: 8 utterances for
+    (a), the bench's batch for (b), 64 utterances for (c); median of 3 after a warm-up."""
+    import statistics
+    from oracle import decode as odec
+    from oracle import mel as omel
+
+    def med(fn, n=3):
+        fn()
+        ts = []
+        for _ in range(n):
+            t0 = time.perf_counter()
+            fn()
+            ts.append(time.perf_counter() - t0)
+        return statistics.median(ts)
+
+    g = torch.Generator().manual_seed(11)
+    N = int(args.seconds * 16000)
+    B = args.batch
+    Tp = ((1 + N // 160) - 1) // 2 + 1
+    wavs = [(0.1 * torch.randn(1, N, generator=g)).clamp(-1, 1) for _ in range(8)]
+    t_mel = med(lambda: omel.collate(wavs))
+    L = int((15.0 if args.vocab == "char" else 4.0) * args.seconds)
+    logits = (torch.randn(Tp, B, V, generator=g) * 3)
+    labels = torch.randint(1, V, (B, L), generator=g)
+    il = torch.full((B,), Tp, dtype=torch.int32)
+    ll = torch.full((B,), L, dtype=torch.int32)
+
+    def ctc():
+        z = logits.clone().requires_grad_(True)
+        torch.nn.functional.ctc_loss(torch.log_softmax(z, 2), labels, il, ll, blank=0).backward()
+    t_ctc = med(ctc)
+    nd = min(64, 2 * B)
+    dlog = torch.randn(nd, Tp, V, generator=g)
+    t_dec = med(lambda: odec.greedy_decode_ids(dlog))
+    return {"frontend_audio_s_per_s": 8 * args.seconds / t_mel,
+            "ctc_fwd_bwd_ms": 1e3 * t_ctc, "ctc_shape_tbv": [Tp, B, V],
+            "greedy_decode_utt_per_s": nd / t_dec, "decode_shape_btv": [nd, Tp, V], "threads": cores}
 
 
 def comm_profile(dp, opt, step, args, world, ms_step_dp):

@@ -63,6 +63,8 @@ constexpr int kRescale = 8;  // K2: frames per rescale block (the exponent measu
 // to 2 * kRescale frames before the next correction lands), while above it a row can only grow 3x per frame
 // (3^16 = 2^26).  f64 then offers ~1900 binary orders below the maximum instead of 1022.
 constexpr int kTopBits = 900;
+constexpr int kAuxDummy = 512;   // doubles of the single-wave kernel's dummy spill row (64 lanes x up to 8 states)
+constexpr int kSingleWaveMaxS = 512;   // lattices up to this many states run on ctc_lattice1_kernel
 
 struct CtcDims {
     int T, B, V, Lmax;
@@ -88,7 +90,7 @@ static CtcDims ctc_dims(int T, int B, int V, int Lmax) {
     d.off_dbl = o;
     o += 2 * ((size_t)2 * B * T * d.SP + B);  // doubles, counted in floats
     d.off_aux = o;                            // single-wave lattice kernel: per (dir, b) a dummy spill
-    o += 2 * ((size_t)2 * B * (256 + T / kRescale + 2));   // row (256 doubles) and the scale E after each block
+    o += 2 * ((size_t)2 * B * (kAuxDummy + T / kRescale + 2));   // row (kAuxDummy doubles) and the scale E after each block
     d.total_floats = o;
     d.total_bytes = o * sizeof(float);
     return d;
@@ -475,7 +477,7 @@ __global__ __launch_bounds__(64 * W) void ctc_lattice_kernel(
 }
 
 // -------------------------------------------------------------------------------------------
-// K2, single-wave lattices (S <= 256: every sentencepiece-sized transcript): the recursion wave is
+// K2, single-wave lattices (S <= 512: every sentencepiece-sized transcript, and 15 s of characters): the recursion wave is
 // issue-bound once the chain is short, so the emission work moves to two HELPER waves of the same
 // workgroup.  Helpers turn the compact log2-prob rows of a chunk of frames into pruned f64
 // emissions y[frame][position] in LDS (double-buffered, one barrier per chunk); the recursion wave
@@ -612,10 +614,10 @@ __global__ __launch_bounds__(192) void ctc_lattice1_kernel(
     // Everything in the frame loop is straight-line: an exec-mask branch costs the serial wave ~30
     // cycles per frame.  Lanes beyond the padded row keep storing into a dummy row (step 0), and the
     // scale is not stored per row but once per rescale block (all lanes write the same value):
-    // aux block of this (dir, b) = dummy[256] | Ecum[T/kRescale + 2].
-    const int aux_stride = 256 + T / kRescale + 2;
+    // aux block of this (dir, b) = dummy[kAuxDummy] | Ecum[T/kRescale + 2].
+    const int aux_stride = kAuxDummy + T / kRescale + 2;
     double* aux_b = aux + ((int64_t)dir * gridDim.x + b) * aux_stride;
-    double* ecum = aux_b + 256;
+    double* ecum = aux_b + kAuxDummy;
     const bool spill_ok = lane * NS < SP;
     // row pointer of the frame being written: walks forward (alpha) or backward (beta) by one row
     double* orow = spill_ok ? out + (int64_t)(dir ? Tb - 1 : 0) * SP + lane * NS : aux_b + lane * NS;
@@ -770,10 +772,10 @@ __global__ __launch_bounds__(256) void ctc_grad_kernel(
         // (multi-wave lattices) or, for the single-wave kernel, Ecum[block] of its aux block
         double gexp = nll2d[b];
         if (aux) {
-            const int aux_stride = 256 + T / kRescale + 2;
+            const int aux_stride = kAuxDummy + T / kRescale + 2;
             const int ka = (t + 1) / kRescale - 1, kb = (Tb - t) / kRescale - 1;   // frame index i: t and Tb-1-t
-            if (ka >= 0) gexp += aux[(int64_t)b * aux_stride + 256 + ka];
-            if (kb >= 0) gexp += aux[((int64_t)B + b) * aux_stride + 256 + kb];
+            if (ka >= 0) gexp += aux[(int64_t)b * aux_stride + kAuxDummy + ka];
+            if (kb >= 0) gexp += aux[((int64_t)B + b) * aux_stride + kAuxDummy + kb];
         } else {
             gexp += arow[SP - 1] + brow[SP - 1];
         }
@@ -899,7 +901,11 @@ extern "C" int sp_ctc_fwd_bwd(const float* logits, int64_t stride_t, int64_t str
                            input_lengths, label_lengths, T, V, blank, max_label_len, d.RW, d.SP, d.modeB, dblw,
                            dblw + (size_t)B * T * d.SP, reinterpret_cast<double*>(ws + d.off_aux),
                            dblw + (size_t)2 * B * T * d.SP, nll);
-    else if (S <= 512) launch_lattice<2, 4>(d, ws, labels, label_stride, input_lengths, label_lengths, blank, nll, s);
+    else if (S <= kSingleWaveMaxS)   // 15 s of characters (L <= 255): eight states per lane, still no barrier per frame
+        hipLaunchKernelGGL((ctc_lattice1_kernel<8>), dim3(B, 2), dim3(192), 0, s, ws + d.off_rows, labels, label_stride,
+                           input_lengths, label_lengths, T, V, blank, max_label_len, d.RW, d.SP, d.modeB, dblw,
+                           dblw + (size_t)B * T * d.SP, reinterpret_cast<double*>(ws + d.off_aux),
+                           dblw + (size_t)2 * B * T * d.SP, nll);
     else if (S <= 1024) launch_lattice<4, 4>(d, ws, labels, label_stride, input_lengths, label_lengths, blank, nll, s);
     else launch_lattice<4, 8>(d, ws, labels, label_stride, input_lengths, label_lengths, blank, nll, s);
     int rc = check_launch("ctc_lattice_kernel");
@@ -911,7 +917,7 @@ extern "C" int sp_ctc_fwd_bwd(const float* logits, int64_t stride_t, int64_t str
 #define SP_GRAD_ARGS logits, stride_t, stride_b, labels, label_stride, input_lengths, label_lengths, T, B, V, blank,   \
                      max_label_len, d.RW, d.SP, d.modeB, ws + d.off_lse, ws + d.off_rows, dbl,                      \
                      dbl + (size_t)B * T * d.SP,                                                                      \
-                     S <= 256 ? reinterpret_cast<const double*>(ws + d.off_aux) : nullptr,                            \
+                     S <= kSingleWaveMaxS ? reinterpret_cast<const double*>(ws + d.off_aux) : nullptr,                            \
                      dbl + (size_t)2 * B * T * d.SP, nll, grad_scale
         if (grad && grad_dtype == SP_BF16)
             hipLaunchKernelGGL((ctc_grad_kernel<__hip_bfloat16>), dim3(gb), dim3(256), lds, s, SP_GRAD_ARGS,

@@ -478,13 +478,13 @@ __global__ __launch_bounds__(64 * W) void ctc_lattice_kernel(
 
 // -------------------------------------------------------------------------------------------
 // K2, single-wave lattices (S <= 512: every sentencepiece-sized transcript, and 15 s of characters): the recursion wave is
-// issue-bound once the chain is short, so the emission work moves to two HELPER waves of the same
+// issue-bound once the chain is short, so the emission work moves to H HELPER waves (2 at two states per lane, 4 at four and eight) of the same
 // workgroup.  Helpers turn the compact log2-prob rows of a chunk of frames into pruned f64
 // emissions y[frame][position] in LDS (double-buffered, one barrier per chunk); the recursion wave
 // only reads them back (ds_read_b128), shifts, adds, multiplies and spills.
 // -------------------------------------------------------------------------------------------
-template <int NS>
-__global__ __launch_bounds__(192) void ctc_lattice1_kernel(
+template <int NS, int H>   // H helper waves (the emissions of a chunk's frames are dealt to them round-robin)
+__global__ __launch_bounds__(64 * (1 + H)) void ctc_lattice1_kernel(
     const float* __restrict__ rows, const int64_t* __restrict__ labels, int label_stride,
     const int32_t* __restrict__ in_len, const int32_t* __restrict__ lab_len, int T, int V,
     int blank, int Lmax, int RW, int SP, int modeB, double* __restrict__ alpha,
@@ -493,7 +493,8 @@ __global__ __launch_bounds__(192) void ctc_lattice1_kernel(
     constexpr int TB = 64 / NS;   // frames per chunk
     constexpr int PW = 64 * NS;   // positions per frame
     constexpr int NK = NS / 2;    // labels per lane
-    constexpr int HF = TB / 2;    // frames per helper wave and chunk
+    constexpr int HF = TB / H;    // frames per helper wave and chunk
+    static_assert(TB % H == 0, "helpers share a chunk's frames evenly");
     __shared__ __attribute__((aligned(16))) double s_y[2][TB][PW];   // 64 KB
     __shared__ int s_rep[64];
     __shared__ double s_fin[2];
@@ -559,7 +560,7 @@ __global__ __launch_bounds__(192) void ctc_lattice1_kernel(
         auto fetch = [&](int c, float (&pb)[HF], float (&pl)[HF][NK]) {
 #pragma unroll
             for (int f = 0; f < HF; ++f) {
-                const int i = min(c * TB + 2 * f + hw, Tb - 1);
+                const int i = min(c * TB + H * f + hw, Tb - 1);
                 const int t = dir ? Tb - 1 - i : i;
                 const float* row = rows_b + (int64_t)t * RW;
                 pb[f] = row[rblank];
@@ -572,7 +573,7 @@ __global__ __launch_bounds__(192) void ctc_lattice1_kernel(
             fetch(min(c + 1, nchunks - 1), nxb, nxl);
 #pragma unroll
             for (int f = 0; f < HF; ++f) {
-                const int i = c * TB + 2 * f + hw;
+                const int i = c * TB + H * f + hw;
                 const int rem = Tb - 1 - i;  // frames left: positions that need more are dead (exact
                                              // pruning: a dead position only ever feeds dead positions)
                 const float xb = fmaxf(lpb[f], -1200.f);
@@ -587,7 +588,7 @@ __global__ __launch_bounds__(192) void ctc_lattice1_kernel(
                     yv[2 * q] = need[2 * q] <= rem ? yb : 0.0;
                     yv[2 * q + 1] = need[2 * q + 1] <= rem ? yl : 0.0;
                 }
-                double* dst = &s_y[c & 1][2 * f + hw][lane * NS];
+                double* dst = &s_y[c & 1][H * f + hw][lane * NS];
 #pragma unroll
                 for (int j = 0; j < NS; j += 2)
                     *reinterpret_cast<double2*>(dst + j) = make_double2(yv[j], yv[j + 1]);
@@ -892,17 +893,17 @@ extern "C" int sp_ctc_fwd_bwd(const float* logits, int64_t stride_t, int64_t str
     // (waves, states per thread): smallest lattice that holds S states
     double* dblw = reinterpret_cast<double*>(ws + d.off_dbl);
     if (S <= 128)
-        hipLaunchKernelGGL((ctc_lattice1_kernel<2>), dim3(B, 2), dim3(192), 0, s, ws + d.off_rows, labels, label_stride,
+        hipLaunchKernelGGL((ctc_lattice1_kernel<2, 2>), dim3(B, 2), dim3(192), 0, s, ws + d.off_rows, labels, label_stride,
                            input_lengths, label_lengths, T, V, blank, max_label_len, d.RW, d.SP, d.modeB, dblw,
                            dblw + (size_t)B * T * d.SP, reinterpret_cast<double*>(ws + d.off_aux),
                            dblw + (size_t)2 * B * T * d.SP, nll);
     else if (S <= 256)
-        hipLaunchKernelGGL((ctc_lattice1_kernel<4>), dim3(B, 2), dim3(192), 0, s, ws + d.off_rows, labels, label_stride,
+        hipLaunchKernelGGL((ctc_lattice1_kernel<4, 4>), dim3(B, 2), dim3(320), 0, s, ws + d.off_rows, labels, label_stride,
                            input_lengths, label_lengths, T, V, blank, max_label_len, d.RW, d.SP, d.modeB, dblw,
                            dblw + (size_t)B * T * d.SP, reinterpret_cast<double*>(ws + d.off_aux),
                            dblw + (size_t)2 * B * T * d.SP, nll);
     else if (S <= kSingleWaveMaxS)   // 15 s of characters (L <= 255): eight states per lane, still no barrier per frame
-        hipLaunchKernelGGL((ctc_lattice1_kernel<8>), dim3(B, 2), dim3(192), 0, s, ws + d.off_rows, labels, label_stride,
+        hipLaunchKernelGGL((ctc_lattice1_kernel<8, 4>), dim3(B, 2), dim3(320), 0, s, ws + d.off_rows, labels, label_stride,
                            input_lengths, label_lengths, T, V, blank, max_label_len, d.RW, d.SP, d.modeB, dblw,
                            dblw + (size_t)B * T * d.SP, reinterpret_cast<double*>(ws + d.off_aux),
                            dblw + (size_t)2 * B * T * d.SP, nll);

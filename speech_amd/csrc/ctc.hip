@@ -1,7 +1,7 @@
 // Fused log-softmax + CTC loss + gradient for gfx950.
 // Replaces train.py:69-77 of the reference (F.log_softmax -> transpose -> torch.nn.CTCLoss).
 //
-// Three launches on one stream (v_exp_f32/v_log_f32 are base-2 natively, so log-probabilities
+// Three launches on the caller's stream (v_exp_f32/v_log_f32 are base-2 natively, so log-probabilities
 // are kept in log2 units):
 //   K1 ctc_rows    (whole chip, one wave per (t,b) row): lse2 = log2 sum_c 2^(z_c*log2e) and the
 //                  compact per-frame row the lattice needs -- either the normalised row itself
@@ -23,8 +23,14 @@
 //                  frames ahead (issue loads early, write to LDS late).  beta is the same
 //                  recursion on the reversed label sequence over reversed time, so there is one
 //                  code path.  Lattice rows are spilled to the workspace in coalesced rows.
-//   K3 ctc_grad    (whole chip, one wave per (t,b) row): posterior per state
-//                  2^(alpha+beta-lp+nll), summed per class in LDS, grad = (softmax - occ)*scale.
+//   K3 gradient.   Single-wave lattices (S <= 512) split it in two.  The DENSE half, softmax(z) * scale over
+//                  the whole vocabulary, needs K1's log-sum-exp only: it rides in K2's launch, in workgroups
+//                  behind the 2B lattice workgroups on the CUs the lattice leaves idle (one workgroup per CU,
+//                  so no streaming wave shares a lattice CU).  The SPARSE half (ctc_sparse) runs after it:
+//                  posterior per state 2^(alpha+beta-lp+nll), summed per class in compact LDS slots, and
+//                  the <= L + 1 touched classes of a frame are overwritten with (p - occ) * scale.
+//                  Larger lattices keep the fused ctc_grad (whole chip, one wave per (t,b) row:
+//                  occupancies per class in LDS, grad = (softmax - occ) * scale).
 //
 // Workspace: lse2[B*T] | rows[B][T][RW] (f32), then f64 alpha[B][T][SP] | beta_rev[B][T][SP] | nll2[B]
 // | aux.  True alpha_t(s) = alpha[b][t][s] * 2^E_t.  SP = 2*Lmax+1 rounded up to 8 > S: the multi-wave
@@ -38,7 +44,9 @@
 // constrained alignments the states that carry the posterior sit hundreds of binary orders below
 // the row maximum (f64 reaches 2^-1022 below it; anything smaller is a posterior of zero).  K3
 // multiplies alpha*beta in f64 and applies 2^(E_a + E_b - log2 y - log2 P) by ldexp.
+#include <algorithm>
 #include <atomic>
+#include <type_traits>
 
 #include "common.h"
 
@@ -63,7 +71,10 @@ constexpr int kRescale = 8;  // K2: frames per rescale block (the exponent measu
 // to 2 * kRescale frames before the next correction lands), while above it a row can only grow 3x per frame
 // (3^16 = 2^26).  f64 then offers ~1900 binary orders below the maximum instead of 1022.
 constexpr int kTopBits = 900;
+constexpr int kCUs = 256;        // MI355X
 constexpr int kAuxDummy = 512;   // doubles of the single-wave kernel's dummy spill row (64 lanes x up to 8 states)
+constexpr int kLat1Threads = 512;      // workgroup of ctc_lattice1_kernel: with kLat1DynLds one workgroup owns a CU
+constexpr int kLat1DynLds = 20 * 1024;  // unused dynamic LDS on top of the 64 KB of emissions: a second workgroup does not fit
 constexpr int kSingleWaveMaxS = 512;   // lattices up to this many states run on ctc_lattice1_kernel
 
 struct CtcDims {
@@ -224,6 +235,20 @@ __device__ __forceinline__ int wave_max_i(int v) {
     v = max(v, __builtin_amdgcn_update_dpp(0, v, 0x140 /*row_mirror*/, 0xF, 0xF, false));
     return max(max(__builtin_amdgcn_readlane(v, 0), __builtin_amdgcn_readlane(v, 16)),
                max(__builtin_amdgcn_readlane(v, 32), __builtin_amdgcn_readlane(v, 48)));
+}
+// wave-wide f32 sum on the VALU only, same association as common.h's butterfly wave_sum (same bits)
+__device__ __forceinline__ float wave_sum_dpp(float v) {
+    auto dpp = [](float x, auto ctrl) {
+        return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), decltype(ctrl)::value, 0xF, 0xF, false));
+    };
+    v += dpp(v, std::integral_constant<int, 0xB1>{});
+    v += dpp(v, std::integral_constant<int, 0x4E>{});
+    v += dpp(v, std::integral_constant<int, 0x141>{});
+    v += dpp(v, std::integral_constant<int, 0x140>{});
+    const int iv = __builtin_bit_cast(int, v);
+    const float r0 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(iv, 0)), r1 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(iv, 16));
+    const float r2 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(iv, 32)), r3 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(iv, 48));
+    return (r0 + r1) + (r2 + r3);
 }
 // 2^(x - shift) as f64 for x <= 0 (a log2-probability; -inf allowed) and integer shift: f32 exp2 of
 // the fraction (in [1,2), 1 ulp), exact f64 ldexp of the integer part.
@@ -476,6 +501,104 @@ __global__ __launch_bounds__(64 * W) void ctc_lattice_kernel(
     }
 }
 
+__device__ __forceinline__ void store4(float* g, int c, float a, float b, float x, float y) {
+    reinterpret_cast<float4*>(g)[c] = make_float4(a, b, x, y);
+}
+__device__ __forceinline__ void store4(__hip_bfloat16* g, int c, float a, float b, float x, float y) {
+    uint2 o;
+    o.x = (uint32_t)__builtin_bit_cast(unsigned short, __float2bfloat16(a)) |
+          ((uint32_t)__builtin_bit_cast(unsigned short, __float2bfloat16(b)) << 16);
+    o.y = (uint32_t)__builtin_bit_cast(unsigned short, __float2bfloat16(x)) |
+          ((uint32_t)__builtin_bit_cast(unsigned short, __float2bfloat16(y)) << 16);
+    reinterpret_cast<uint2*>(g)[c] = o;
+}
+
+// The DENSE half of the gradient: softmax(z) * scale over the whole vocabulary, zero rows beyond an utterance's
+// length.  It needs K1's log-sum-exp only, so it does not wait for the lattice: the workgroups behind the 2B lattice
+// workgroups of ctc_lattice1_kernel's grid run it on the CUs (and the memory bandwidth) the lattice leaves idle.
+// (id, n) = this wave's index among the n waves that share the rows.
+template <typename G>
+__device__ __forceinline__ void ctc_dense_rows(
+    const float* __restrict__ logits, int64_t st, int64_t sb, const int32_t* __restrict__ in_len,
+    const int32_t* __restrict__ lab_len, int T, int B, int V, int Lmax, const float* __restrict__ lse2,
+    float grad_scale, G* __restrict__ grad, int id, int n, int lane) {
+    const bool vec = ((V & 3) == 0) && ((st & 3) == 0) && ((sb & 3) == 0) &&
+                     ((reinterpret_cast<uintptr_t>(logits) | reinterpret_cast<uintptr_t>(grad)) & 15) == 0;
+    const int64_t nrows = (int64_t)T * B;
+    const bool tmaj = st > sb;   // rows are walked in memory order: neighbouring waves then touch neighbouring lines
+    // the arguments are log2-probabilities (<= 0 up to rounding): the bare v_exp_f32 (probabilities below 2^-126
+    // flush to zero) instead of exp2f's denormal-safe sequence, which made this half VALU-bound at two waves per SIMD
+    if (vec && V <= 1024) {
+        // few waves run this (two workgroups per CU): each keeps kR rows = up to 16 KB in flight
+        constexpr int kR = 4;
+        const int nc = V >> 2;
+        for (int64_t r0 = (int64_t)id * kR; r0 < nrows; r0 += (int64_t)n * kR) {
+            float4 zz[kR][4];
+            float l2[kR], scale[kR];
+            bool live[kR];
+            G* g[kR];
+#pragma unroll
+            for (int q = 0; q < kR; ++q) {
+                const int64_t r = min(r0 + q, nrows - 1);
+                const int b = tmaj ? (int)(r % B) : (int)(r / T), t = tmaj ? (int)(r / B) : (int)(r % T);
+                const float4* z4 = reinterpret_cast<const float4*>(logits + t * st + b * sb);
+#pragma unroll
+                for (int c = 0; c < 4; ++c) zz[q][c] = z4[min(lane + 64 * c, nc - 1)];
+                const int Tb = min(max(in_len[b], 0), T);
+                const int L = min(max(lab_len[b], 0), Lmax);
+                live[q] = t < Tb;   // rows beyond the utterance's length are zeros
+                scale[q] = grad_scale / ((float)B * (float)max(L, 1));
+                l2[q] = lse2[(int64_t)b * T + t];
+                g[q] = grad + t * st + b * sb;
+            }
+#pragma unroll
+            for (int q = 0; q < kR; ++q) {
+                if (r0 + q >= nrows) break;
+#pragma unroll
+                for (int c = 0; c < 4; ++c) {
+                    if (lane + 64 * c >= nc) continue;
+                    if (!live[q]) {
+                        store4(g[q], lane + 64 * c, 0.f, 0.f, 0.f, 0.f);
+                    } else {
+                        const float4 v = zz[q][c];
+                        store4(g[q], lane + 64 * c, __builtin_amdgcn_exp2f(fmaf(v.x, kLog2e, -l2[q])) * scale[q],
+                               __builtin_amdgcn_exp2f(fmaf(v.y, kLog2e, -l2[q])) * scale[q], __builtin_amdgcn_exp2f(fmaf(v.z, kLog2e, -l2[q])) * scale[q],
+                               __builtin_amdgcn_exp2f(fmaf(v.w, kLog2e, -l2[q])) * scale[q]);
+                    }
+                }
+            }
+        }
+        return;
+    }
+    for (int64_t r = id; r < nrows; r += n) {
+        const int b = tmaj ? (int)(r % B) : (int)(r / T), t = tmaj ? (int)(r / B) : (int)(r % T);
+        const int Tb = min(max(in_len[b], 0), T);
+        G* g = grad + t * st + b * sb;
+        if (t >= Tb) {
+            if (vec) {
+                for (int c = lane; c < (V >> 2); c += 64) store4(g, c, 0.f, 0.f, 0.f, 0.f);
+            } else {
+                for (int c = lane; c < V; c += 64) Elem<G>::st(g + c, 0.f);
+            }
+            continue;
+        }
+        const int L = min(max(lab_len[b], 0), Lmax);
+        const float scale = grad_scale / ((float)B * (float)max(L, 1));
+        const float* z = logits + t * st + b * sb;
+        const float l2 = lse2[(int64_t)b * T + t];
+        if (vec) {
+            const float4* z4 = reinterpret_cast<const float4*>(z);
+            for (int c = lane; c < (V >> 2); c += 64) {
+                const float4 zz = z4[c];
+                store4(g, c, exp2f(fmaf(zz.x, kLog2e, -l2)) * scale, exp2f(fmaf(zz.y, kLog2e, -l2)) * scale,
+                       exp2f(fmaf(zz.z, kLog2e, -l2)) * scale, exp2f(fmaf(zz.w, kLog2e, -l2)) * scale);
+            }
+        } else {
+            for (int c = lane; c < V; c += 64) Elem<G>::st(g + c, exp2f(fmaf(z[c], kLog2e, -l2)) * scale);
+        }
+    }
+}
+
 // -------------------------------------------------------------------------------------------
 // K2, single-wave lattices (S <= 512: every sentencepiece-sized transcript, and 15 s of characters): the recursion wave is
 // issue-bound once the chain is short, so the emission work moves to H HELPER waves (2 at two states per lane, 4 at four and eight) of the same
@@ -484,12 +607,25 @@ __global__ __launch_bounds__(64 * W) void ctc_lattice_kernel(
 // only reads them back (ds_read_b128), shifts, adds, multiplies and spills.
 // -------------------------------------------------------------------------------------------
 template <int NS, int H>   // H helper waves (the emissions of a chunk's frames are dealt to them round-robin)
-__global__ __launch_bounds__(64 * (1 + H)) void ctc_lattice1_kernel(
+__global__ __launch_bounds__(kLat1Threads) void ctc_lattice1_kernel(
     const float* __restrict__ rows, const int64_t* __restrict__ labels, int label_stride,
     const int32_t* __restrict__ in_len, const int32_t* __restrict__ lab_len, int T, int V,
     int blank, int Lmax, int RW, int SP, int modeB, double* __restrict__ alpha,
     double* __restrict__ beta_rev, double* __restrict__ aux, double* __restrict__ nll2,
-    float* __restrict__ nll) {
+    float* __restrict__ nll, int B, const float* __restrict__ logits, int64_t st, int64_t sb,
+    const float* __restrict__ lse2, float grad_scale, void* __restrict__ grad, int grad_bf16) {
+    // grid = 2B lattice workgroups (placed first), then the workgroups of the gradient's dense half
+    if ((int)blockIdx.x >= 2 * B) {
+        constexpr int nw = kLat1Threads / 64;
+        const int id = ((int)blockIdx.x - 2 * B) * nw + (int)(threadIdx.x >> 6), n = ((int)gridDim.x - 2 * B) * nw;
+        if (grad_bf16)
+            ctc_dense_rows(logits, st, sb, in_len, lab_len, T, B, V, Lmax, lse2, grad_scale, (__hip_bfloat16*)grad, id, n,
+                           (int)(threadIdx.x & 63));
+        else
+            ctc_dense_rows(logits, st, sb, in_len, lab_len, T, B, V, Lmax, lse2, grad_scale, (float*)grad, id, n,
+                           (int)(threadIdx.x & 63));
+        return;
+    }
     constexpr int TB = 64 / NS;   // frames per chunk
     constexpr int PW = 64 * NS;   // positions per frame
     constexpr int NK = NS / 2;    // labels per lane
@@ -499,7 +635,7 @@ __global__ __launch_bounds__(64 * (1 + H)) void ctc_lattice1_kernel(
     __shared__ int s_rep[64];
     __shared__ double s_fin[2];
 
-    const int b = blockIdx.x, dir = blockIdx.y;
+    const int b = (int)blockIdx.x % B, dir = (int)blockIdx.x / B;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int Tb = min(max(in_len[b], 0), T);
     const int L = min(max(lab_len[b], 0), Lmax);
@@ -512,6 +648,14 @@ __global__ __launch_bounds__(64 * (1 + H)) void ctc_lattice1_kernel(
             nll[b] = (L == 0) ? 0.f : INFINITY;
             nll2[b] = (L == 0) ? 0.0 : (double)INFINITY;
         }
+        return;
+    }
+    if (wave > H) {
+        // The workgroup is as large as the dense half wants it (eight waves, one workgroup per CU: a lattice CU then
+        // holds no streaming waves, which slowed the recursion to half its pace through the CU's memory pipeline).
+        // The lattice's spare waves only keep the barrier count: one for the set-up below, one per chunk.
+        const int nch = (Tb + TB - 1) / TB;
+        for (int c = 0; c <= nch; ++c) __syncthreads();
         return;
     }
 
@@ -605,6 +749,8 @@ __global__ __launch_bounds__(64 * (1 + H)) void ctc_lattice1_kernel(
     }
 
     // ---------------------------------------------------------------------- recursion wave
+    // the serial chain outranks the streaming waves of the dense half that may share its SIMD
+    __builtin_amdgcn_s_setprio(3);
     double* out = (dir ? beta_rev : alpha) + (int64_t)b * T * SP;
     // a(-1) = delta(position 0): one step of the general recurrence then yields the CTC start
     // condition (positions 0 and 1 take their emission, everything else 0)
@@ -617,7 +763,7 @@ __global__ __launch_bounds__(64 * (1 + H)) void ctc_lattice1_kernel(
     // scale is not stored per row but once per rescale block (all lanes write the same value):
     // aux block of this (dir, b) = dummy[kAuxDummy] | Ecum[T/kRescale + 2].
     const int aux_stride = kAuxDummy + T / kRescale + 2;
-    double* aux_b = aux + ((int64_t)dir * gridDim.x + b) * aux_stride;
+    double* aux_b = aux + ((int64_t)dir * B + b) * aux_stride;
     double* ecum = aux_b + kAuxDummy;
     const bool spill_ok = lane * NS < SP;
     // row pointer of the frame being written: walks forward (alpha) or backward (beta) by one row
@@ -707,18 +853,6 @@ __global__ __launch_bounds__(64 * (1 + H)) void ctc_lattice1_kernel(
 // -------------------------------------------------------------------------------------------
 // K3: gradient rows (+ the scalar loss in block 0)
 // -------------------------------------------------------------------------------------------
-__device__ __forceinline__ void store4(float* g, int c, float a, float b, float x, float y) {
-    reinterpret_cast<float4*>(g)[c] = make_float4(a, b, x, y);
-}
-__device__ __forceinline__ void store4(__hip_bfloat16* g, int c, float a, float b, float x, float y) {
-    uint2 o;
-    o.x = (uint32_t)__builtin_bit_cast(unsigned short, __float2bfloat16(a)) |
-          ((uint32_t)__builtin_bit_cast(unsigned short, __float2bfloat16(b)) << 16);
-    o.y = (uint32_t)__builtin_bit_cast(unsigned short, __float2bfloat16(x)) |
-          ((uint32_t)__builtin_bit_cast(unsigned short, __float2bfloat16(y)) << 16);
-    reinterpret_cast<uint2*>(g)[c] = o;
-}
-
 // G = element type of the gradient (float, or bf16 when the consumer is a bf16 GEMM: the rounding the
 // caller would apply in a pass of its own happens in the store)
 template <typename G>
@@ -825,6 +959,160 @@ __global__ __launch_bounds__(256) void ctc_grad_kernel(
     }
 }
 
+// K3 in two halves (single-wave lattices).  The DENSE half (ctc_dense_rows) has already run inside the lattice
+// launch.  The SPARSE half runs after it: per frame it forms the state posteriors exactly as ctc_grad_kernel does and
+// overwrites the <= L + 1 classes that carry any (label classes and blank) with (p - occupancy) * scale, p taken
+// from K1's compact log2-prob row: the same f32 expression the fused kernel evaluates, so the two routes agree bit
+// for bit.  One wave = kR consecutive frames of one utterance: the label classes are read once, the alpha / beta /
+// log-prob values of all kR frames are in flight together (a single row per wave left the kernel latency-bound:
+// 26 us for 46 MB), and the occupancies are summed in compact per-frame slots (slot 0 = blank, slot 1 + k = the
+// first label position that carries position k's class), so nothing V-sized is cleared.
+// NI = lattice states per lane (S <= 64 NI).
+template <typename G, int NI, int kR>
+__global__ __launch_bounds__(256) void ctc_sparse_kernel(
+    int64_t st, int64_t sb, const int64_t* __restrict__ labels, int label_stride,
+    const int32_t* __restrict__ in_len, const int32_t* __restrict__ lab_len, int T, int B, int V, int blank,
+    int Lmax, int RW, int SP, int modeB, const float* __restrict__ rows, const double* __restrict__ alpha,
+    const double* __restrict__ beta_rev, const double* __restrict__ aux, const double* __restrict__ nll2d,
+    const float* __restrict__ nll, float grad_scale, G* __restrict__ grad, float* __restrict__ loss) {
+    extern __shared__ __attribute__((aligned(16))) float s_dyn[];  // per wave: first[V] (int) | acc[kR][AL]
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int wpb = blockDim.x >> 6;
+
+    if (blockIdx.x == 0 && wave == 0 && loss) {
+        float acc = 0.f;
+        for (int b = lane; b < B; b += 64) acc += nll[b] / (float)max(min(lab_len[b], Lmax), 1);
+        acc = wave_sum(acc);
+        if (lane == 0) loss[0] = acc / (float)B;
+    }
+    if (!grad) return;
+
+    const int AL = Lmax + 2;
+    int* first = reinterpret_cast<int*>(s_dyn + (size_t)wave * (V + kR * AL));
+    float* acc = reinterpret_cast<float*>(first + V);
+    const int groups = (T + kR - 1) / kR;
+    const int64_t nitems = (int64_t)B * groups;
+    const int aux_stride = kAuxDummy + T / kRescale + 2;
+    for (int64_t it = (int64_t)blockIdx.x * wpb + wave; it < nitems; it += (int64_t)gridDim.x * wpb) {
+        const int b = (int)(it / groups), t0 = (int)(it % groups) * kR;
+        const int Tb = min(max(in_len[b], 0), T);
+        if (t0 >= Tb) continue;
+        const int L = min(max(lab_len[b], 0), Lmax);
+        const int S = 2 * L + 1;
+        const float scale = grad_scale / ((float)B * (float)max(L, 1));
+        const int64_t* lab = labels + (int64_t)b * label_stride;
+
+        // ---- every load of the item is issued before anything waits: classes, then kR frames of alpha / beta / log-probs
+        int cls[NI], ri[NI];
+#pragma unroll
+        for (int i = 0; i < NI; ++i) {
+            const int s_ = lane + 64 * i;
+            cls[i] = blank;
+            if ((s_ & 1) && s_ < S) cls[i] = min(max((int)lab[(s_ - 1) >> 1], 0), V - 1);
+        }
+        double av[kR][NI], bv[kR][NI], gexp[kR];
+        const double gbase = nll2d[b];
+#pragma unroll
+        for (int q = 0; q < kR; ++q) {
+            const int t = min(t0 + q, Tb - 1);
+            const double* arow = alpha + ((int64_t)b * T + t) * SP;
+            const double* brow = beta_rev + ((int64_t)b * T + t) * SP;
+#pragma unroll
+            for (int i = 0; i < NI; ++i) {
+                const int s_ = min(lane + 64 * i, S - 1);
+                av[q][i] = arow[s_];
+                bv[q][i] = brow[S - 1 - s_];
+            }
+            // 2^gexp * alpha_hat * beta_hat / y = the state posterior (Ecum of the two rescale blocks, see ctc_grad_kernel)
+            const int ka = (t + 1) / kRescale - 1, kb = (Tb - t) / kRescale - 1;
+            double ge = gbase;
+            if (ka >= 0) ge += aux[(int64_t)b * aux_stride + kAuxDummy + ka];
+            if (kb >= 0) ge += aux[((int64_t)B + b) * aux_stride + kAuxDummy + kb];
+            gexp[q] = ge;
+        }
+        float lr[kR][NI];
+#pragma unroll
+        for (int i = 0; i < NI; ++i) {
+            const int s_ = lane + 64 * i;
+            ri[i] = modeB ? cls[i] : ((s_ & 1) ? (s_ + 1) >> 1 : 0);
+            if (s_ >= S) ri[i] = 0;
+        }
+#pragma unroll
+        for (int q = 0; q < kR; ++q) {
+            const float* lrow = rows + ((int64_t)b * T + min(t0 + q, Tb - 1)) * RW;
+#pragma unroll
+            for (int i = 0; i < NI; ++i) lr[q][i] = lrow[ri[i]];
+        }
+
+        // ---- slot of every label position: the first position with its class
+        __builtin_amdgcn_wave_barrier();   // the previous item's reads of first[] / acc[] are done
+#pragma unroll
+        for (int i = NI - 1; i >= 0; --i) {   // descending positions: the lowest position of a class writes last ...
+            const int s_ = lane + 64 * i;
+            if ((s_ & 1) && s_ < S) first[cls[i]] = (s_ - 1) >> 1;
+        }
+        __builtin_amdgcn_wave_barrier();
+        // ... across lanes and iterations the surviving writer is whichever the hardware ordered last: any ONE
+        // position per class serves, every position of the class reads the same survivor
+        int slot[NI];
+#pragma unroll
+        for (int i = 0; i < NI; ++i) {
+            const int s_ = lane + 64 * i;
+            slot[i] = ((s_ & 1) && s_ < S) ? 1 + first[cls[i]] : 0;
+        }
+        for (int c = lane; c < kR * AL; c += 64) acc[c] = 0.f;
+        __builtin_amdgcn_wave_barrier();
+
+        // ---- posteriors of the kR frames into their slots
+        float blank_acc[kR];
+#pragma unroll
+        for (int q = 0; q < kR; ++q) {
+            blank_acc[q] = 0.f;
+#pragma unroll
+            for (int i = 0; i < NI; ++i) {
+                const int s_ = lane + 64 * i;
+                // alpha_hat and beta_hat can each sit ~1000 binary orders below their row maxima where the
+                // posterior peaks: multiply mantissas, add exponents, one ldexp
+                const double gq = gexp[q] - (double)lr[q][i];
+                const double gn = floor(gq);
+                int xa, xb;
+                const double ma = frexp(av[q][i], &xa), mb = frexp(bv[q][i], &xb);
+                const double pr = ma * mb * (double)__builtin_amdgcn_exp2f((float)(gq - gn));
+                const double ge = fmax(fmin(gn + (double)(xa + xb), 4000.0), -4000.0);
+                float gam = (float)ldexp(pr, (int)ge);
+                if (s_ >= S || t0 + q >= Tb) gam = 0.f;
+                if (s_ & 1) {
+                    if (gam != 0.f) atomicAdd(&acc[q * AL + slot[i]], gam);
+                } else {
+                    blank_acc[q] += gam;
+                }
+            }
+        }
+#pragma unroll
+        for (int q = 0; q < kR; ++q) blank_acc[q] = wave_sum_dpp(blank_acc[q]);   // kR independent chains
+        if (lane < kR) {
+            float v = blank_acc[0];
+#pragma unroll
+            for (int q = 1; q < kR; ++q) v = (lane == q) ? blank_acc[q] : v;
+            acc[lane * AL] = v;   // slot 0 is the blank's alone
+        }
+        __builtin_amdgcn_wave_barrier();
+
+        // ---- overwrite the touched classes (every position of a class stores the same value)
+#pragma unroll
+        for (int q = 0; q < kR; ++q) {
+            if (t0 + q >= Tb) break;
+            G* g = grad + (int64_t)(t0 + q) * st + b * sb;
+#pragma unroll
+            for (int i = 0; i < NI; ++i) {
+                const int s_ = lane + 64 * i;
+                if (s_ >= S || (!(s_ & 1) && s_ != 0)) continue;   // one store for the blank class
+                Elem<G>::st(g + cls[i], (exp2f(lr[q][i]) - acc[q * AL + slot[i]]) * scale);
+            }
+        }
+    }
+}
+
 template <int W, int NS>
 static void launch_lattice(const CtcDims& d, float* ws, const int64_t* labels, int label_stride,
                            const int32_t* in_len, const int32_t* lab_len, int blank, float* nll,
@@ -892,41 +1180,65 @@ extern "C" int sp_ctc_fwd_bwd(const float* logits, int64_t stride_t, int64_t str
     const int S = 2 * max_label_len + 1;
     // (waves, states per thread): smallest lattice that holds S states
     double* dblw = reinterpret_cast<double*>(ws + d.off_dbl);
+    // single-wave lattices carry the dense half of the gradient in the same launch: workgroups behind the 2B lattice
+    // workgroups, one per CU the lattice leaves free (rows are dealt statically, so a workgroup that had to wait for
+    // a CU would finish last); the sparse half follows
+    const bool have_grad = grad && T > 0;
+    const bool split = have_grad && S <= kSingleWaveMaxS;
+    const int dense_blocks = split ? std::max(kCUs - 2 * B, kCUs / 4) : 0;
+#define SP_LAT1_ARGS ws + d.off_rows, labels, label_stride, input_lengths, label_lengths, T, V, blank, max_label_len, d.RW, \
+                     d.SP, d.modeB, dblw, dblw + (size_t)B * T * d.SP, reinterpret_cast<double*>(ws + d.off_aux),           \
+                     dblw + (size_t)2 * B * T * d.SP, nll, B, logits, stride_t, stride_b, ws + d.off_lse, grad_scale, grad,  \
+                     grad_dtype == SP_BF16 ? 1 : 0
     if (S <= 128)
-        hipLaunchKernelGGL((ctc_lattice1_kernel<2, 2>), dim3(B, 2), dim3(192), 0, s, ws + d.off_rows, labels, label_stride,
-                           input_lengths, label_lengths, T, V, blank, max_label_len, d.RW, d.SP, d.modeB, dblw,
-                           dblw + (size_t)B * T * d.SP, reinterpret_cast<double*>(ws + d.off_aux),
-                           dblw + (size_t)2 * B * T * d.SP, nll);
+        hipLaunchKernelGGL((ctc_lattice1_kernel<2, 2>), dim3(2 * B + dense_blocks), dim3(kLat1Threads), kLat1DynLds, s, SP_LAT1_ARGS);
     else if (S <= 256)
-        hipLaunchKernelGGL((ctc_lattice1_kernel<4, 4>), dim3(B, 2), dim3(320), 0, s, ws + d.off_rows, labels, label_stride,
-                           input_lengths, label_lengths, T, V, blank, max_label_len, d.RW, d.SP, d.modeB, dblw,
-                           dblw + (size_t)B * T * d.SP, reinterpret_cast<double*>(ws + d.off_aux),
-                           dblw + (size_t)2 * B * T * d.SP, nll);
+        hipLaunchKernelGGL((ctc_lattice1_kernel<4, 4>), dim3(2 * B + dense_blocks), dim3(kLat1Threads), kLat1DynLds, s, SP_LAT1_ARGS);
     else if (S <= kSingleWaveMaxS)   // 15 s of characters (L <= 255): eight states per lane, still no barrier per frame
-        hipLaunchKernelGGL((ctc_lattice1_kernel<8, 4>), dim3(B, 2), dim3(320), 0, s, ws + d.off_rows, labels, label_stride,
-                           input_lengths, label_lengths, T, V, blank, max_label_len, d.RW, d.SP, d.modeB, dblw,
-                           dblw + (size_t)B * T * d.SP, reinterpret_cast<double*>(ws + d.off_aux),
-                           dblw + (size_t)2 * B * T * d.SP, nll);
+        hipLaunchKernelGGL((ctc_lattice1_kernel<8, 4>), dim3(2 * B + dense_blocks), dim3(kLat1Threads), kLat1DynLds, s, SP_LAT1_ARGS);
     else if (S <= 1024) launch_lattice<4, 4>(d, ws, labels, label_stride, input_lengths, label_lengths, blank, nll, s);
     else launch_lattice<4, 8>(d, ws, labels, label_stride, input_lengths, label_lengths, blank, nll, s);
+#undef SP_LAT1_ARGS
     int rc = check_launch("ctc_lattice_kernel");
     if (rc) return rc;
 
     if (grad || loss) {
-        const int gb = (grad && T > 0) ? row_blocks : 1;
+        const int gb = have_grad ? row_blocks : 1;
         const size_t lds = (size_t)4 * V * sizeof(float);
+        const double* auxp = S <= kSingleWaveMaxS ? reinterpret_cast<const double*>(ws + d.off_aux) : nullptr;
+        if (split) {
+#define SP_GRAD_ARGS stride_t, stride_b, labels, label_stride, input_lengths, label_lengths, T, B, V, blank, max_label_len,  \
+                     d.RW, d.SP, d.modeB, ws + d.off_rows, dbl, dbl + (size_t)B * T * d.SP, auxp,                            \
+                     dbl + (size_t)2 * B * T * d.SP, nll, grad_scale
+#define SP_SPARSE(NI, R)                                                                                                     \
+    do {                                                                                                                     \
+        const int64_t items = (int64_t)B * ((T + R - 1) / R);                                                                \
+        const int sg = (int)std::min<int64_t>((items + 3) / 4, 8192);                                                        \
+        const size_t sl = (size_t)4 * (V + R * (max_label_len + 2)) * sizeof(float);                                         \
+        if (grad_dtype == SP_BF16)                                                                                           \
+            hipLaunchKernelGGL((ctc_sparse_kernel<__hip_bfloat16, NI, R>), dim3(sg), dim3(256), sl, s, SP_GRAD_ARGS,         \
+                               (__hip_bfloat16*)grad, loss);                                                                 \
+        else                                                                                                                 \
+            hipLaunchKernelGGL((ctc_sparse_kernel<float, NI, R>), dim3(sg), dim3(256), sl, s, SP_GRAD_ARGS, (float*)grad,    \
+                               loss);                                                                                        \
+    } while (0)
+            if (S <= 128) SP_SPARSE(2, 4);
+            else if (S <= 256) SP_SPARSE(4, 4);
+            else SP_SPARSE(8, 2);
+#undef SP_SPARSE
+#undef SP_GRAD_ARGS
+        } else {
 #define SP_GRAD_ARGS logits, stride_t, stride_b, labels, label_stride, input_lengths, label_lengths, T, B, V, blank,   \
                      max_label_len, d.RW, d.SP, d.modeB, ws + d.off_lse, ws + d.off_rows, dbl,                      \
-                     dbl + (size_t)B * T * d.SP,                                                                      \
-                     S <= kSingleWaveMaxS ? reinterpret_cast<const double*>(ws + d.off_aux) : nullptr,                            \
-                     dbl + (size_t)2 * B * T * d.SP, nll, grad_scale
-        if (grad && grad_dtype == SP_BF16)
-            hipLaunchKernelGGL((ctc_grad_kernel<__hip_bfloat16>), dim3(gb), dim3(256), lds, s, SP_GRAD_ARGS,
-                               T > 0 ? (__hip_bfloat16*)grad : nullptr, loss);
-        else
-            hipLaunchKernelGGL((ctc_grad_kernel<float>), dim3(gb), dim3(256), lds, s, SP_GRAD_ARGS,
-                               T > 0 ? (float*)grad : nullptr, loss);
+                     dbl + (size_t)B * T * d.SP, auxp, dbl + (size_t)2 * B * T * d.SP, nll, grad_scale
+            if (grad && grad_dtype == SP_BF16)
+                hipLaunchKernelGGL((ctc_grad_kernel<__hip_bfloat16>), dim3(gb), dim3(256), lds, s, SP_GRAD_ARGS,
+                                   T > 0 ? (__hip_bfloat16*)grad : nullptr, loss);
+            else
+                hipLaunchKernelGGL((ctc_grad_kernel<float>), dim3(gb), dim3(256), lds, s, SP_GRAD_ARGS,
+                                   T > 0 ? (float*)grad : nullptr, loss);
 #undef SP_GRAD_ARGS
+        }
         rc = check_launch("ctc_grad_kernel");
         if (rc) return rc;
     }

@@ -277,6 +277,46 @@ def test_ctc_seeded_vs_oracles(cuda, cfg):
     assert np.abs(grad[:, feasible] - rgrad.numpy()[:, feasible]).max() <= 1e-4 * gmax + 2 * ref32_err + 1e-12
 
 
+@pytest.mark.parametrize("cfg", [(203, 5, 1000, 60), (203, 5, 1000, 120), (150, 4, 600, 250), (203, 5, 29, 60),
+                                 (97, 3, 31, 7), (2, 2, 1000, 1), (1, 3, 50, 1)])
+def test_ctc_split_gradient_repeats_and_ragged(cuda, cfg):
+    """Single-wave lattices form the gradient in two halves (softmax over the vocabulary beside the lattice, then the
+    label classes' occupancies): labels that repeat a class many times (adjacent and apart), ragged input lengths
+    that cut the frame groups of the sparse half anywhere, every states-per-lane variant, class- and position-indexed
+    rows; against torch CPU float64, and zero rows beyond each length."""
+    T, B, V, L = cfg
+    g = torch.Generator().manual_seed(T * 7 + L)
+    logits = torch.randn(T, B, V, generator=g) * 3
+    labels = torch.randint(1, V, (B, L), generator=g)
+    labels[0, : max(L // 2, 1)] = 5                       # one class over and over (mandatory blanks between)
+    if L >= 6:
+        labels[1, ::3] = 7                                 # the same class apart
+        labels[1, 1::3] = 9
+    ll = torch.randint(max(L // 2, 1), L + 1, (B,), generator=g).int()
+    ll[0] = max(L // 2, 1)
+    il = torch.full((B,), T, dtype=torch.int32)
+    if T > 8:
+        il[1] = T - 1
+        il[2] = T - 6
+        il[-1] = T - 3
+    for b in range(B):                                     # keep every utterance feasible
+        need = int(ll[b]) + int((labels[b, 1:int(ll[b])] == labels[b, :int(ll[b]) - 1]).sum())
+        while need > int(il[b]):
+            ll[b] -= 1
+            need = int(ll[b]) + int((labels[b, 1:int(ll[b])] == labels[b, :int(ll[b]) - 1]).sum())
+    ll.clamp_(min=1)
+    loss, nll, grad = _ctc_hip(cuda, logits, labels, il, ll, max_label_len=L)
+    rl, rnll, g64 = octc.ctc_torch(logits, labels, il, ll, dtype=torch.float64)
+    feasible = np.isfinite(rnll.numpy())
+    assert feasible.any()
+    assert np.allclose(nll[feasible], rnll.numpy()[feasible], rtol=1e-4, atol=1e-5)
+    g64 = g64.numpy()
+    gmax = np.abs(g64[:, feasible]).max()
+    assert np.abs(grad[:, feasible] - g64[:, feasible]).max() <= 1e-4 * gmax + 1e-12
+    for b in range(B):
+        assert np.all(grad[int(il[b]):, b] == 0)
+
+
 def test_ctc_autograd_wrapper(cuda):
     from speech_amd import ops
     g = torch.Generator().manual_seed(3)

@@ -1182,22 +1182,24 @@ extern "C" int sp_ctc_fwd_bwd(const float* logits, int64_t stride_t, int64_t str
     double* dblw = reinterpret_cast<double*>(ws + d.off_dbl);
     // single-wave lattices carry the dense half of the gradient in the same launch: workgroups behind the 2B lattice
     // workgroups, one per CU the lattice leaves free (rows are dealt statically, so a workgroup that had to wait for
-    // a CU would finish last); the sparse half follows
+    // a CU would finish last); the sparse half follows.  Only while the lattice leaves at least half of the chip:
+    // larger batches run the lattice two workgroups to a CU and the fused gradient kernel on the whole chip after it.
     const bool have_grad = grad && T > 0;
-    const bool split = have_grad && S <= kSingleWaveMaxS;
-    const int dense_blocks = split ? std::max(kCUs - 2 * B, kCUs / 4) : 0;
+    const bool split = have_grad && S <= kSingleWaveMaxS && 4 * B <= kCUs;
+    const int dense_blocks = split ? kCUs - 2 * B : 0;
 #define SP_LAT1_ARGS ws + d.off_rows, labels, label_stride, input_lengths, label_lengths, T, V, blank, max_label_len, d.RW, \
                      d.SP, d.modeB, dblw, dblw + (size_t)B * T * d.SP, reinterpret_cast<double*>(ws + d.off_aux),           \
                      dblw + (size_t)2 * B * T * d.SP, nll, B, logits, stride_t, stride_b, ws + d.off_lse, grad_scale, grad,  \
                      grad_dtype == SP_BF16 ? 1 : 0
-    if (S <= 128)
-        hipLaunchKernelGGL((ctc_lattice1_kernel<2, 2>), dim3(2 * B + dense_blocks), dim3(kLat1Threads), kLat1DynLds, s, SP_LAT1_ARGS);
-    else if (S <= 256)
-        hipLaunchKernelGGL((ctc_lattice1_kernel<4, 4>), dim3(2 * B + dense_blocks), dim3(kLat1Threads), kLat1DynLds, s, SP_LAT1_ARGS);
-    else if (S <= kSingleWaveMaxS)   // 15 s of characters (L <= 255): eight states per lane, still no barrier per frame
-        hipLaunchKernelGGL((ctc_lattice1_kernel<8, 4>), dim3(2 * B + dense_blocks), dim3(kLat1Threads), kLat1DynLds, s, SP_LAT1_ARGS);
+#define SP_LAT1(NS, H)                                                                                                       \
+    hipLaunchKernelGGL((ctc_lattice1_kernel<NS, H>), dim3(2 * B + dense_blocks), dim3(split ? kLat1Threads : 64 * (1 + H)),  \
+                       split ? kLat1DynLds : 0, s, SP_LAT1_ARGS)
+    if (S <= 128) SP_LAT1(2, 2);
+    else if (S <= 256) SP_LAT1(4, 4);
+    else if (S <= kSingleWaveMaxS) SP_LAT1(8, 4);   // 15 s of characters (L <= 255): eight states per lane, still no barrier per frame
     else if (S <= 1024) launch_lattice<4, 4>(d, ws, labels, label_stride, input_lengths, label_lengths, blank, nll, s);
     else launch_lattice<4, 8>(d, ws, labels, label_stride, input_lengths, label_lengths, blank, nll, s);
+#undef SP_LAT1
 #undef SP_LAT1_ARGS
     int rc = check_launch("ctc_lattice_kernel");
     if (rc) return rc;

@@ -795,11 +795,13 @@ __global__ __launch_bounds__(kLat1Threads) void ctc_lattice1_kernel(
         const int nsteps = min(TB, Tb - c * TB);
         int k0 = 0;
         for (; k0 + kRescale <= nsteps; k0 += kRescale) {   // full blocks: straight-line code
-            // exponent of the current maximum, folded into the block's last frame
-            double m = a[0];
+            // exponent of the current maximum, folded into the block's last frame.  The states are non-negative, so
+            // their high words order like the values: one integer max per state instead of canonicalising f64
+            // maxima, and the exponent field is cut out of the wave's maximum on the scalar unit
+            int mh = __double2hiint(a[0]);
 #pragma unroll
-            for (int j = 1; j < NS; ++j) m = fmax(m, a[j]);
-            const int e = wave_max_i((__double2hiint(m) >> 20) & 0x7FF);
+            for (int j = 1; j < NS; ++j) mh = max(mh, __double2hiint(a[j]));
+            const int e = (wave_max_i(mh) >> 20) & 0x7FF;
             const int dp = e ? e - (1023 + kTopBits) : 0;
             double y[kRescale][NS];
 #pragma unroll

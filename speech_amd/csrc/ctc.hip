@@ -33,7 +33,8 @@
 //                  occupancies per class in LDS, grad = (softmax - occ) * scale).
 //
 // Workspace: lse2[B*T] | rows[B][T][RW] (f32), then f64 alpha[B][T][SP] | beta_rev[B][T][SP] | nll2[B]
-// | aux.  True alpha_t(s) = alpha[b][t][s] * 2^E_t.  SP = 2*Lmax+1 rounded up to 8 > S: the multi-wave
+// | aux.  True alpha_t(s) = alpha[b][t][s] * 2^E_t.  SP = 2*Lmax+1 rounded up to 8 > S (512 and in spill_col order for
+// the lattices of 257..512 states): the multi-wave
 // kernel keeps E_t in slot SP-1 of the row; the single-wave kernel writes E once per 8-frame block
 // into its aux block (and parks the stores of lanes beyond SP on a dummy row there).
 //
@@ -77,10 +78,20 @@ constexpr int kLat1Threads = 512;      // workgroup of ctc_lattice1_kernel: with
 constexpr int kLat1DynLds = 20 * 1024;  // unused dynamic LDS on top of the 64 KB of emissions: a second workgroup does not fit
 constexpr int kSingleWaveMaxS = 512;   // lattices up to this many states run on ctc_lattice1_kernel
 
+// Column of lattice state p in a spilled row.  The kernel with eight states per lane stores a lane's four state pairs
+// 1 KB apart ([pair][lane][2]: each of its four stores per frame is one contiguous KB; with a lane's 64 bytes side by
+// side in the row, every store touched all of the row's 64-byte sectors a quarter each and the recursion paid 35 us
+// of 141 for it; at four states per lane the same change measured nothing); 64 consecutive states are then whole
+// 128-byte lines, so the consumers' reads stay coalesced.
+__device__ __forceinline__ int spill_col(int p, int perm) {   // perm = log2(states per lane) of the producer, or 0
+    return perm ? ((p & ((1 << perm) - 2)) << 6) + ((p >> perm) << 1) + (p & 1) : p;
+}
+
 struct CtcDims {
     int T, B, V, Lmax;
     int RW;    // row width in floats (multiple of 4)
     int SP;    // padded lattice row (multiple of 8)
+    int perm;  // rows in the store order of the kernel with 2^perm states per lane (spill_col); 0: in state order
     int modeB; // 1: rows indexed by class, 0: by label position
     size_t off_lse, off_rows, total_floats;  // float offsets
     size_t off_dbl;  // float offset of the f64 block: alpha[B][T][SP] | beta_rev[B][T][SP] | nll2[B]
@@ -93,7 +104,9 @@ static CtcDims ctc_dims(int T, int B, int V, int Lmax) {
     d.T = T; d.B = B; d.V = V; d.Lmax = Lmax;
     d.modeB = V <= Lmax + 1;
     d.RW = (int)align_up((size_t)(d.modeB ? V : Lmax + 1), 4);
-    d.SP = (int)align_up((size_t)(2 * Lmax + 1), 8);
+    const int S = 2 * Lmax + 1;
+    d.perm = (S > 256 && S <= kSingleWaveMaxS) ? 3 : 0;   // measured: no gain at four states per lane
+    d.SP = d.perm ? 64 << d.perm : (int)align_up((size_t)S, 8);   // permuted rows: every lane has its columns
     size_t o = 0;
     d.off_lse = o; o += align_up((size_t)B * T, 4);
     d.off_rows = o; o += (size_t)B * T * d.RW;
@@ -631,6 +644,9 @@ __global__ __launch_bounds__(kLat1Threads) void ctc_lattice1_kernel(
     constexpr int NK = NS / 2;    // labels per lane
     constexpr int HF = TB / H;    // frames per helper wave and chunk
     static_assert(TB % H == 0, "helpers share a chunk's frames evenly");
+    // emissions as [buffer][frame][state pair][lane][2]: a lane's pairs lie 1 KB apart, so every 16-byte read or write
+    // of a wave is one contiguous KB (lane * NS doubles apart, the reads of four / eight states per lane hit the same
+    // banks two / four times over)
     __shared__ __attribute__((aligned(16))) double s_y[2][TB][PW];   // 64 KB
     __shared__ int s_rep[64];
     __shared__ double s_fin[2];
@@ -732,10 +748,10 @@ __global__ __launch_bounds__(kLat1Threads) void ctc_lattice1_kernel(
                     yv[2 * q] = need[2 * q] <= rem ? yb : 0.0;
                     yv[2 * q + 1] = need[2 * q + 1] <= rem ? yl : 0.0;
                 }
-                double* dst = &s_y[c & 1][H * f + hw][lane * NS];
+                double* dst = &s_y[c & 1][H * f + hw][lane * 2];
 #pragma unroll
                 for (int j = 0; j < NS; j += 2)
-                    *reinterpret_cast<double2*>(dst + j) = make_double2(yv[j], yv[j + 1]);
+                    *reinterpret_cast<double2*>(dst + j * 64) = make_double2(yv[j], yv[j + 1]);
             }
 #pragma unroll
             for (int f = 0; f < HF; ++f) {
@@ -765,9 +781,10 @@ __global__ __launch_bounds__(kLat1Threads) void ctc_lattice1_kernel(
     const int aux_stride = kAuxDummy + T / kRescale + 2;
     double* aux_b = aux + ((int64_t)dir * B + b) * aux_stride;
     double* ecum = aux_b + kAuxDummy;
-    const bool spill_ok = lane * NS < SP;
+    constexpr bool kPerm = NS == 8;   // spill_col order (the row pitch is then 64 NS: every lane has its columns)
+    const bool spill_ok = kPerm || lane * NS < SP;
     // row pointer of the frame being written: walks forward (alpha) or backward (beta) by one row
-    double* orow = spill_ok ? out + (int64_t)(dir ? Tb - 1 : 0) * SP + lane * NS : aux_b + lane * NS;
+    double* orow = spill_ok ? out + (int64_t)(dir ? Tb - 1 : 0) * SP + lane * (kPerm ? 2 : NS) : aux_b + lane * NS;
     const int64_t ostep = spill_ok ? (dir ? -(int64_t)SP : (int64_t)SP) : 0;
     auto step = [&](const double (&yq)[NS]) {
         const double p1 = lane_shr1(a[NS - 1]);
@@ -786,7 +803,8 @@ __global__ __launch_bounds__(kLat1Threads) void ctc_lattice1_kernel(
     };
     auto spill = [&]() {   // one vector-memory op per lane and frame (NS == 2)
 #pragma unroll
-        for (int j = 0; j < NS; j += 2) *reinterpret_cast<double2*>(orow + j) = make_double2(a[j], a[j + 1]);
+        for (int j = 0; j < NS; j += 2)
+            *reinterpret_cast<double2*>(orow + (kPerm ? j * 64 : j)) = make_double2(a[j], a[j + 1]);
         orow += ostep;
     };
     int i = 0;
@@ -806,10 +824,10 @@ __global__ __launch_bounds__(kLat1Threads) void ctc_lattice1_kernel(
             double y[kRescale][NS];
 #pragma unroll
             for (int q = 0; q < kRescale; ++q) {
-                const double* src = &s_y[c & 1][k0 + q][lane * NS];
+                const double* src = &s_y[c & 1][k0 + q][lane * 2];
 #pragma unroll
                 for (int j = 0; j < NS; j += 2) {
-                    const double2 v = *reinterpret_cast<const double2*>(src + j);
+                    const double2 v = *reinterpret_cast<const double2*>(src + j * 64);
                     y[q][j] = v.x;
                     y[q][j + 1] = v.y;
                 }
@@ -827,9 +845,9 @@ __global__ __launch_bounds__(kLat1Threads) void ctc_lattice1_kernel(
         }
         for (; k0 < nsteps; ++k0, ++i) {   // tail frames of the sequence: no rescale
             double yq[NS];
-            const double* src = &s_y[c & 1][k0][lane * NS];
+            const double* src = &s_y[c & 1][k0][lane * 2];
 #pragma unroll
-            for (int j = 0; j < NS; ++j) yq[j] = src[j];
+            for (int j = 0; j < NS; ++j) yq[j] = src[(j >> 1) * 128 + (j & 1)];
             step(yq);
             spill();
         }
@@ -865,7 +883,7 @@ __global__ __launch_bounds__(256) void ctc_grad_kernel(
     const float* __restrict__ lse2, const float* __restrict__ rows, const double* __restrict__ alpha,
     const double* __restrict__ beta_rev, const double* __restrict__ aux,
     const double* __restrict__ nll2d, const float* __restrict__ nll, float grad_scale,
-    G* __restrict__ grad, float* __restrict__ loss) {
+    G* __restrict__ grad, float* __restrict__ loss, int perm) {
     extern __shared__ __attribute__((aligned(16))) float s_occ[];  // [waves][V]
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int wpb = blockDim.x >> 6;
@@ -929,7 +947,7 @@ __global__ __launch_bounds__(256) void ctc_grad_kernel(
             const double gq = gexp - (double)lrow[ri];
             const double gn = floor(gq);
             int xa, xb;
-            const double ma = frexp(arow[s], &xa), mb = frexp(brow[S - 1 - s], &xb);
+            const double ma = frexp(arow[spill_col(s, perm)], &xa), mb = frexp(brow[spill_col(S - 1 - s, perm)], &xb);
             const double pr = ma * mb * (double)__builtin_amdgcn_exp2f((float)(gq - gn));
             const double ge = fmax(fmin(gn + (double)(xa + xb), 4000.0), -4000.0);
             const float gam = (float)ldexp(pr, (int)ge);
@@ -976,7 +994,7 @@ __global__ __launch_bounds__(256) void ctc_sparse_kernel(
     const int32_t* __restrict__ in_len, const int32_t* __restrict__ lab_len, int T, int B, int V, int blank,
     int Lmax, int RW, int SP, int modeB, const float* __restrict__ rows, const double* __restrict__ alpha,
     const double* __restrict__ beta_rev, const double* __restrict__ aux, const double* __restrict__ nll2d,
-    const float* __restrict__ nll, float grad_scale, G* __restrict__ grad, float* __restrict__ loss) {
+    const float* __restrict__ nll, float grad_scale, G* __restrict__ grad, float* __restrict__ loss, int perm) {
     extern __shared__ __attribute__((aligned(16))) float s_dyn[];  // per wave: first[V] (int) | acc[kR][AL]
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int wpb = blockDim.x >> 6;
@@ -1022,8 +1040,8 @@ __global__ __launch_bounds__(256) void ctc_sparse_kernel(
 #pragma unroll
             for (int i = 0; i < NI; ++i) {
                 const int s_ = min(lane + 64 * i, S - 1);
-                av[q][i] = arow[s_];
-                bv[q][i] = brow[S - 1 - s_];
+                av[q][i] = arow[spill_col(s_, perm)];
+                bv[q][i] = brow[spill_col(S - 1 - s_, perm)];
             }
             // 2^gexp * alpha_hat * beta_hat / y = the state posterior (Ecum of the two rescale blocks, see ctc_grad_kernel)
             const int ka = (t + 1) / kRescale - 1, kb = (Tb - t) / kRescale - 1;
@@ -1221,10 +1239,10 @@ extern "C" int sp_ctc_fwd_bwd(const float* logits, int64_t stride_t, int64_t str
         const size_t sl = (size_t)4 * (V + R * (max_label_len + 2)) * sizeof(float);                                         \
         if (grad_dtype == SP_BF16)                                                                                           \
             hipLaunchKernelGGL((ctc_sparse_kernel<__hip_bfloat16, NI, R>), dim3(sg), dim3(256), sl, s, SP_GRAD_ARGS,         \
-                               (__hip_bfloat16*)grad, loss);                                                                 \
+                               (__hip_bfloat16*)grad, loss, d.perm);                                                                 \
         else                                                                                                                 \
             hipLaunchKernelGGL((ctc_sparse_kernel<float, NI, R>), dim3(sg), dim3(256), sl, s, SP_GRAD_ARGS, (float*)grad,    \
-                               loss);                                                                                        \
+                               loss, d.perm);                                                                                     \
     } while (0)
             if (S <= 128) SP_SPARSE(2, 4);
             else if (S <= 256) SP_SPARSE(4, 4);
@@ -1237,10 +1255,10 @@ extern "C" int sp_ctc_fwd_bwd(const float* logits, int64_t stride_t, int64_t str
                      dbl + (size_t)B * T * d.SP, auxp, dbl + (size_t)2 * B * T * d.SP, nll, grad_scale
             if (grad && grad_dtype == SP_BF16)
                 hipLaunchKernelGGL((ctc_grad_kernel<__hip_bfloat16>), dim3(gb), dim3(256), lds, s, SP_GRAD_ARGS,
-                                   T > 0 ? (__hip_bfloat16*)grad : nullptr, loss);
+                                   T > 0 ? (__hip_bfloat16*)grad : nullptr, loss, d.perm);
             else
                 hipLaunchKernelGGL((ctc_grad_kernel<float>), dim3(gb), dim3(256), lds, s, SP_GRAD_ARGS,
-                                   T > 0 ? (float*)grad : nullptr, loss);
+                                   T > 0 ? (float*)grad : nullptr, loss, d.perm);
 #undef SP_GRAD_ARGS
         }
         rc = check_launch("ctc_grad_kernel");

@@ -278,12 +278,13 @@ def test_ctc_seeded_vs_oracles(cuda, cfg):
 
 
 @pytest.mark.parametrize("cfg", [(203, 5, 1000, 60), (203, 5, 1000, 120), (150, 4, 600, 250), (203, 5, 29, 60),
-                                 (97, 3, 31, 7), (2, 2, 1000, 1), (1, 3, 50, 1), (40, 70, 1000, 6)])
+                                 (97, 3, 31, 7), (2, 2, 1000, 1), (1, 3, 50, 1), (40, 70, 1000, 6), (300, 66, 29, 130)])
 def test_ctc_split_gradient_repeats_and_ragged(cuda, cfg):
     """Single-wave lattices form the gradient in two halves (softmax over the vocabulary beside the lattice, then the
     label classes' occupancies): labels that repeat a class many times (adjacent and apart), ragged input lengths
     that cut the frame groups of the sparse half anywhere, every states-per-lane variant, class- and position-indexed
-    rows, and a batch above 64 (single-wave lattice two workgroups to a CU + the fused gradient kernel); against torch
+    rows, and batches above 64 (single-wave lattice two workgroups to a CU + the fused gradient kernel, also on the
+    eight-states-per-lane kernel's permuted rows); against torch
     CPU float64, and zero rows beyond each length."""
     T, B, V, L = cfg
     g = torch.Generator().manual_seed(T * 7 + L)

@@ -63,7 +63,7 @@ constexpr int kMaxDevices = 64;
 static std::atomic<void*> g_scratch_ptr[kMaxDevices];
 
 constexpr float kLog2e = 1.4426950408889634f;
-constexpr int kMaxV = 4000;  // K3 keeps 4 x V floats of per-class sums in LDS (<= 64 KB)
+constexpr int kMaxV = 4000;  // K3 keeps 4 x V floats (fused) or ints + a few label-sized rows (sparse half) in LDS: <= 72 KB
 constexpr int kMaxL = 1023;
 constexpr int kPF = 8;  // float4 prefetch registers per thread in K2
 constexpr int kRescale = 8;  // K2: frames per rescale block (the exponent measured at its start is applied in its last frame)

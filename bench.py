@@ -147,6 +147,14 @@ def kernel_rooflines(args, model, wav, offs, labels, lens, Lmax, V, iters):
     # (the kernels spill f64 alpha AND beta -- 4x that term -- for the precision DESIGN.md section 4 explains;
     # the roofline fraction is quoted against the algorithmic bytes, so that choice costs fraction, as it should)
     line("ctc_fwd_bwd(3 kernels)", 2 * 4.0 * Tp * B * V + 2 * 4.0 * Tp * S, ms, 1)
+    # the form the training step runs: time-major logits, gradient stored as bf16 for the classifier's bf16 GEMM
+    logits_t = logits.transpose(0, 1).contiguous()
+    grad16 = torch.empty_like(logits_t, dtype=torch.bfloat16)
+    ms = time_kernel(lambda: check(L.sp_ctc_fwd_bwd(ptr(logits_t), logits_t.stride(0), logits_t.stride(1), ptr(labels),
+                                                    labels.stride(0), ptr(il), ptr(lens), Tp, B, V, 0, Lmax, 1.0,
+                                                    ptr(nll), ptr(loss), ptr(grad16), 2, ptr(ws), ws.numel(), st), "ctc"), iters)
+    line("ctc_fwd_bwd(as in the step: time-major, bf16 gradient)", (4.0 + 2.0) * Tp * B * V + 2 * 4.0 * Tp * S, ms, 0)   # counted above
+    del logits_t, grad16
     # decode: scores read + ids write
     ids = torch.empty((B, Tp), dtype=torch.int32, device=dev); nids = torch.empty(B, dtype=torch.int32, device=dev)
     ms = time_kernel(lambda: check(L.sp_greedy_decode(ptr(logits), _lib.dtype_code(logits), B, Tp, V, 0, None, ptr(ids),

@@ -1256,8 +1256,8 @@ extern "C" int sp_ctc_fwd_bwd(const float* logits, int64_t stride_t, int64_t str
                                loss, d.perm);                                                                                     \
     } while (0)
             if (S <= 128) SP_SPARSE(2, 4);
-            else if (S <= 256) SP_SPARSE(4, 4);
-            else SP_SPARSE(8, 2);
+            else if (S <= 256) SP_SPARSE(4, 2);
+            else SP_SPARSE(8, 1);   // registers: one frame per wave at eight states per lane (47 against 60 us)
 #undef SP_SPARSE
 #undef SP_GRAD_ARGS
         } else {

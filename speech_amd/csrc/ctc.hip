@@ -1255,7 +1255,7 @@ extern "C" int sp_ctc_fwd_bwd(const float* logits, int64_t stride_t, int64_t str
             hipLaunchKernelGGL((ctc_sparse_kernel<float, NI, R>), dim3(sg), dim3(256), sl, s, SP_GRAD_ARGS, (float*)grad,    \
                                loss, d.perm);                                                                                     \
     } while (0)
-            if (S <= 128) SP_SPARSE(2, 4);
+            if (S <= 128) SP_SPARSE(2, 2);   // measured at 32 x 751 x 1000: 19.9 / 18.5 / 21.4 us at 1 / 2 / 4 frames per wave
             else if (S <= 256) SP_SPARSE(4, 2);
             else SP_SPARSE(8, 1);   // registers: one frame per wave at eight states per lane (47 against 60 us)
 #undef SP_SPARSE

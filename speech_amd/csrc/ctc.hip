@@ -106,7 +106,9 @@ static CtcDims ctc_dims(int T, int B, int V, int Lmax) {
     d.RW = (int)align_up((size_t)(d.modeB ? V : Lmax + 1), 4);
     const int S = 2 * Lmax + 1;
     d.perm = (S > 256 && S <= kSingleWaveMaxS) ? 3 : 0;   // measured: no gain at four states per lane
-    d.SP = d.perm ? 64 << d.perm : (int)align_up((size_t)S, 8);   // permuted rows: every lane has its columns
+    // permuted rows and the lattices of two states per lane: every lane has its columns (pitch 64 x states per lane),
+    // so the recursion wave's row pointer is one scalar walked by a scalar stride
+    d.SP = d.perm ? 64 << d.perm : S <= 128 ? 128 : (int)align_up((size_t)S, 8);
     size_t o = 0;
     d.off_lse = o; o += align_up((size_t)B * T, 4);
     d.off_rows = o; o += (size_t)B * T * d.RW;
@@ -781,11 +783,18 @@ __global__ __launch_bounds__(kLat1Threads) void ctc_lattice1_kernel(
     const int aux_stride = kAuxDummy + T / kRescale + 2;
     double* aux_b = aux + ((int64_t)dir * B + b) * aux_stride;
     double* ecum = aux_b + kAuxDummy;
-    constexpr bool kPerm = NS == 8;   // spill_col order (the row pitch is then 64 NS: every lane has its columns)
-    const bool spill_ok = kPerm || lane * NS < SP;
+    constexpr bool kPerm = NS == 8;   // spill_col order
+    constexpr bool kAllLanes = NS != 4;   // the row pitch is 64 NS (ctc_dims): every lane has its columns
+    const bool spill_ok = kAllLanes || lane * NS < SP;
     // row pointer of the frame being written: walks forward (alpha) or backward (beta) by one row
     double* orow = spill_ok ? out + (int64_t)(dir ? Tb - 1 : 0) * SP + lane * (kPerm ? 2 : NS) : aux_b + lane * NS;
     const int64_t ostep = spill_ok ? (dir ? -(int64_t)SP : (int64_t)SP) : 0;
+    // kAllLanes: buffer stores -- the utterance's rows behind one descriptor, the row as a scalar byte offset walked by
+    // scalar adds, the lane's column as a fixed vector offset: no vector instruction per frame goes into addressing
+    const auto orsrc = __builtin_amdgcn_make_buffer_rsrc((void*)out, 0, (int)((int64_t)T * SP * 8), 0x00020000);
+    int osoff = (dir ? Tb - 1 : 0) * SP * 8;
+    const int ostep_b = (dir ? -SP : SP) * 8;
+    const int loff = lane * (kPerm ? 16 : NS * 8);
     auto step = [&](const double (&yq)[NS]) {
         const double p1 = lane_shr1(a[NS - 1]);
         double n_[NS];
@@ -803,9 +812,17 @@ __global__ __launch_bounds__(kLat1Threads) void ctc_lattice1_kernel(
     };
     auto spill = [&]() {   // one vector-memory op per lane and frame (NS == 2)
 #pragma unroll
-        for (int j = 0; j < NS; j += 2)
-            *reinterpret_cast<double2*>(orow + (kPerm ? j * 64 : j)) = make_double2(a[j], a[j + 1]);
-        orow += ostep;
+        for (int j = 0; j < NS; j += 2) {
+            if constexpr (kAllLanes) {
+                using d2 = __attribute__((ext_vector_type(2))) double;
+                using u4 = __attribute__((ext_vector_type(4))) unsigned;
+                const d2 v = {a[j], a[j + 1]};
+                __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u4, v), orsrc, loff + (kPerm ? j * 512 : j * 8), osoff, 0);
+            } else
+                *reinterpret_cast<double2*>(orow + j) = make_double2(a[j], a[j + 1]);
+        }
+        if constexpr (kAllLanes) osoff += ostep_b;
+        else orow += ostep;
     };
     int i = 0;
     for (int c = 0; c < nchunks; ++c) {

@@ -1226,12 +1226,12 @@ extern "C" int sp_ctc_fwd_bwd(const float* logits, int64_t stride_t, int64_t str
     // How many: the dense half should END with the lattice, not race it -- with all free CUs streaming, the recursion
     // lost 10 % (32 x 751: 41.8 us with 96 dense workgroups, 43.8 with 160, 45.5 with 192) although no streaming wave
     // shares its CUs.  A CU streams ~32 GB/s of rows that the Infinity Cache still holds and ~22 GB/s from HBM; the
-    // lattice takes 55 / 110 / 140 ns per frame at 2 / 4 / 8 states per lane.  Only the four-rows-in-flight path is
+    // lattice takes 52 / 110 / 125 ns per frame at 2 / 4 / 8 states per lane.  Only the four-rows-in-flight path is
     // sized this way: the generic one (odd or large V) is latency-bound per wave and takes every free CU.
     int dense_blocks = split ? kCUs - 2 * B : 0;
     if (split && V % 4 == 0 && V <= 1024) {
         const double bytes = (double)T * B * V * (4 + (grad_dtype == SP_BF16 ? 2 : 4));
-        const double t_lat = (double)T * (S <= 128 ? 55e-9 : S <= 256 ? 110e-9 : 140e-9);
+        const double t_lat = (double)T * (S <= 128 ? 52e-9 : S <= 256 ? 110e-9 : 125e-9);
         const double per_cu = bytes > 200e6 ? 22e9 : 32e9;
         dense_blocks = std::min(dense_blocks, std::max(32, (int)(1.3 * bytes / (t_lat * per_cu)) + 1));
     }
@@ -1242,7 +1242,12 @@ extern "C" int sp_ctc_fwd_bwd(const float* logits, int64_t stride_t, int64_t str
 #define SP_LAT1(NS, H)                                                                                                       \
     hipLaunchKernelGGL((ctc_lattice1_kernel<NS, H>), dim3(2 * B + dense_blocks), dim3(split ? kLat1Threads : 64 * (1 + H)),  \
                        split ? kLat1DynLds : 0, s, SP_LAT1_ARGS)
-    if (S <= 128) SP_LAT1(2, 2);
+    if (S <= 128) {
+        // four helper waves when the workgroup has a CU to itself (two could not keep up with the recursion: 43.4 ->
+        // 39.7 us at 32 x 751 x 1000); two where two workgroups share a CU's registers
+        if (split) SP_LAT1(2, 4);
+        else SP_LAT1(2, 2);
+    }
     else if (S <= 256) SP_LAT1(4, 4);
     else if (S <= kSingleWaveMaxS) SP_LAT1(8, 4);   // 15 s of characters (L <= 255): eight states per lane, still no barrier per frame
     else if (S <= 1024) launch_lattice<4, 4>(d, ws, labels, label_stride, input_lengths, label_lengths, blank, nll, s);

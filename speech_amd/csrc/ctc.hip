@@ -1226,12 +1226,12 @@ extern "C" int sp_ctc_fwd_bwd(const float* logits, int64_t stride_t, int64_t str
     // How many: the dense half should END with the lattice, not race it -- with all free CUs streaming, the recursion
     // lost 10 % (32 x 751: 41.8 us with 96 dense workgroups, 43.8 with 160, 45.5 with 192) although no streaming wave
     // shares its CUs.  A CU streams ~32 GB/s of rows that the Infinity Cache still holds and ~22 GB/s from HBM; the
-    // lattice takes 52 / 110 / 125 ns per frame at 2 / 4 / 8 states per lane.  Only the four-rows-in-flight path is
+    // lattice takes 52 / 76 / 125 ns per frame at 2 / 4 / 8 states per lane.  Only the four-rows-in-flight path is
     // sized this way: the generic one (odd or large V) is latency-bound per wave and takes every free CU.
     int dense_blocks = split ? kCUs - 2 * B : 0;
     if (split && V % 4 == 0 && V <= 1024) {
         const double bytes = (double)T * B * V * (4 + (grad_dtype == SP_BF16 ? 2 : 4));
-        const double t_lat = (double)T * (S <= 128 ? 52e-9 : S <= 256 ? 110e-9 : 125e-9);
+        const double t_lat = (double)T * (S <= 128 ? 52e-9 : S <= 256 ? 76e-9 : 125e-9);
         const double per_cu = bytes > 200e6 ? 22e9 : 32e9;
         dense_blocks = std::min(dense_blocks, std::max(32, (int)(1.3 * bytes / (t_lat * per_cu)) + 1));
     }

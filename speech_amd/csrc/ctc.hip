@@ -1000,10 +1000,10 @@ __global__ __launch_bounds__(256) void ctc_grad_kernel(
 // launch.  The SPARSE half runs after it: per frame it forms the state posteriors exactly as ctc_grad_kernel does and
 // overwrites the <= L + 1 classes that carry any (label classes and blank) with (p - occupancy) * scale, p taken
 // from K1's compact log2-prob row: the same f32 expression the fused kernel evaluates, so the two routes agree bit
-// for bit.  One wave = kR consecutive frames of one utterance: the label classes are read once, the alpha / beta /
+// for bit (up to the association of the blank states' sum).  One wave = kR consecutive frames of one utterance: the label classes are read once, the alpha / beta /
 // log-prob values of all kR frames are in flight together (a single row per wave left the kernel latency-bound:
-// 26 us for 46 MB), and the occupancies are summed in compact per-frame slots (slot 0 = blank, slot 1 + k = the
-// first label position that carries position k's class), so nothing V-sized is cleared.
+// 26 us for 46 MB), and the occupancies are summed in compact per-frame slots (slot 0 = blank, slot 1 + k = one
+// label position that carries position k's class), so nothing V-sized is cleared.
 // NI = lattice states per lane (S <= 64 NI).
 template <typename G, int NI, int kR>
 __global__ __launch_bounds__(256) void ctc_sparse_kernel(
@@ -1081,16 +1081,15 @@ __global__ __launch_bounds__(256) void ctc_sparse_kernel(
             for (int i = 0; i < NI; ++i) lr[q][i] = lrow[ri[i]];
         }
 
-        // ---- slot of every label position: the first position with its class
+        // ---- slot of every label position: ONE position of its class (whichever write the LDS ordered last: every
+        // position of the class reads the same survivor; the wave's LDS operations execute in order)
         __builtin_amdgcn_wave_barrier();   // the previous item's reads of first[] / acc[] are done
 #pragma unroll
-        for (int i = NI - 1; i >= 0; --i) {   // descending positions: the lowest position of a class writes last ...
+        for (int i = 0; i < NI; ++i) {
             const int s_ = lane + 64 * i;
             if ((s_ & 1) && s_ < S) first[cls[i]] = (s_ - 1) >> 1;
         }
         __builtin_amdgcn_wave_barrier();
-        // ... across lanes and iterations the surviving writer is whichever the hardware ordered last: any ONE
-        // position per class serves, every position of the class reads the same survivor
         int slot[NI];
 #pragma unroll
         for (int i = 0; i < NI; ++i) {

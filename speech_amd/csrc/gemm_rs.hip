@@ -35,19 +35,6 @@ typedef uint32_t rs_u32x4 __attribute__((ext_vector_type(4)));
 typedef __attribute__((address_space(1))) const void* rs_gptr_t;
 typedef __attribute__((address_space(3))) void* rs_lptr_t;
 
-#ifndef SP_NT_PIPE
-#define SP_NT_PIPE 1
-#endif
-#ifndef SP_NT_LAB_NODMA
-#define SP_NT_LAB_NODMA 0
-#endif
-#ifndef SP_NT_LAB_NOMFMA
-#define SP_NT_LAB_NOMFMA 0
-#endif
-#ifndef SP_NT_PF
-#define SP_NT_PF 0
-#endif
-
 template <int N> struct IC { static constexpr int v = N; };
 template <int... Is, class F> __device__ __forceinline__ void static_for_impl(std::integer_sequence<int, Is...>, F&& f) {
     (f(IC<Is>{}), ...);
@@ -151,7 +138,7 @@ __global__ __launch_bounds__(768, 3) void gemm_nt_rs_kernel(RsArgs g) {
             const __hip_bfloat16* ap = g.A + ak * 64;
 #pragma unroll
             for (int i = 0; i < PA; ++i)
-                if (!SP_NT_LAB_NODMA) __builtin_amdgcn_global_load_lds((rs_gptr_t)(ap + a_off[i]), (rs_lptr_t)(st + i * 4096), 16, 0, 0);
+                __builtin_amdgcn_global_load_lds((rs_gptr_t)(ap + a_off[i]), (rs_lptr_t)(st + i * 4096), 16, 0, 0);
             if (++ak == nk) {
                 ak = 0;
                 atile += tl.nslots;
@@ -163,44 +150,13 @@ __global__ __launch_bounds__(768, 3) void gemm_nt_rs_kernel(RsArgs g) {
             const __hip_bfloat16* bp = g.B + bk * 64;
 #pragma unroll
             for (int i = 0; i < PB; ++i)
-                if (!SP_NT_LAB_NODMA) __builtin_amdgcn_global_load_lds((rs_gptr_t)(bp + b_off[i]), (rs_lptr_t)(st + i * 4096), 16, 0, 0);
+                __builtin_amdgcn_global_load_lds((rs_gptr_t)(bp + b_off[i]), (rs_lptr_t)(st + i * 4096), 16, 0, 0);
             if (++bk == nk) {
                 bk = 0;
                 btile += tl.nslots;
                 if (btile < tl.run1) set_b(btile);
             }
         };
-#if SP_NT_PF
-        // L2 prefetch of the A rows the DMA will ask for SP_NT_PF steps from now, by SCALAR loads (they do not pass
-        // through the vector L1, whose 64 outstanding lines are what paces the DMA): this CU takes a quarter of the
-        // tile's rows (the four column tiles that share an A panel run side by side in one XCD), a loader wave a
-        // quarter of those, both 64-byte halves of each 128-byte line.
-        int ptile = tl.first, pk = NSTA - 1 + SP_NT_PF;
-        while (pk >= nk) { pk -= nk; ptile += tl.nslots; }
-        constexpr int RPW = BM / 16;          // rows per loader wave
-        static_assert(RPW == 12 || RPW == 16, "prefetch rows");
-        uint32_t sink[24];
-#pragma unroll
-        for (int i = 0; i < 24; ++i) sink[i] = 0;
-        auto prefetchA = [&]() {
-            // the previous call's loads have long landed; this wait is what tells the compiler that their destination
-            // registers were in use until here
-            asm volatile("s_waitcnt lgkmcnt(0)" : "+s"(sink[0]), "+s"(sink[1]), "+s"(sink[2]), "+s"(sink[3]), "+s"(sink[4]), "+s"(sink[5]),
-                         "+s"(sink[6]), "+s"(sink[7]), "+s"(sink[8]), "+s"(sink[9]), "+s"(sink[10]), "+s"(sink[11]));
-            asm volatile("" : "+s"(sink[12]), "+s"(sink[13]), "+s"(sink[14]), "+s"(sink[15]), "+s"(sink[16]), "+s"(sink[17]),
-                         "+s"(sink[18]), "+s"(sink[19]), "+s"(sink[20]), "+s"(sink[21]), "+s"(sink[22]), "+s"(sink[23]));
-            if (ptile < tl.run1) {
-                const int r0 = tl.tile_m(ptile) * BM + (tl.tile_n(ptile) & 3) * (BM / 4) + lw * RPW;
-#pragma unroll
-                for (int i = 0; i < 12; ++i) {
-                    const __hip_bfloat16* rp = g.A + (int64_t)min(r0 + i, g.M - 1) * g.lda + pk * 64;
-                    asm volatile("s_load_dword %0, %1, 0x0" : "=s"(sink[2 * i]) : "s"(rp));
-                    asm volatile("s_load_dword %0, %1, 0x40" : "=s"(sink[2 * i + 1]) : "s"(rp));
-                }
-            }
-            if (++pk == nk) { pk = 0; ptile += tl.nslots; }
-        };
-#endif
         // prologue: A(0) [A(1)], B(0)
         issueA(0);
         if (NSTA == 3) issueA(1);
@@ -209,24 +165,15 @@ __global__ __launch_bounds__(768, 3) void gemm_nt_rs_kernel(RsArgs g) {
         for (int step = 0; step < total; ++step) {
             // in flight may stay: nothing (NSTA = 2) or this wave's share of A(step + 1), issued after B(step)
             if (step == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NSTA == 3 && !SP_NT_LAB_NODMA ? PA : 0) : "memory");
+            else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NSTA == 3 ? PA : 0) : "memory");
             __builtin_amdgcn_s_barrier();    // B_step: the stages of `step` are complete, those of step - 1 free
             asm volatile("" ::: "memory");
             issueB(fb);                      // B(step + 1)
             issueA(fa);                      // A(step + NSTA - 1)
-#if SP_NT_PF
-            prefetchA();
-#endif
             fb ^= 1;
             fa = fa + 1 == NSTA ? 0 : fa + 1;
         }
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // nothing may land after the workgroup's LDS is released
-#if SP_NT_PF
-        asm volatile("s_waitcnt lgkmcnt(0)" : "+s"(sink[0]), "+s"(sink[1]), "+s"(sink[2]), "+s"(sink[3]), "+s"(sink[4]), "+s"(sink[5]),
-                     "+s"(sink[6]), "+s"(sink[7]), "+s"(sink[8]), "+s"(sink[9]), "+s"(sink[10]), "+s"(sink[11]));
-        asm volatile("" : "+s"(sink[12]), "+s"(sink[13]), "+s"(sink[14]), "+s"(sink[15]), "+s"(sink[16]), "+s"(sink[17]),
-                     "+s"(sink[18]), "+s"(sink[19]), "+s"(sink[20]), "+s"(sink[21]), "+s"(sink[22]), "+s"(sink[23]));
-#endif
         return;
     }
 
@@ -234,7 +181,6 @@ __global__ __launch_bounds__(768, 3) void gemm_nt_rs_kernel(RsArgs g) {
     const int wm = wave / WNW, wn = wave % WNW;
     const int li = lane & 15, q = lane >> 4;
     const int swz = (li >> 1) & 7;
-#if SP_NT_PIPE
     // Software-pipelined K step, written instruction by instruction (the compiler placed every fragment read
     // right in front of the MFMAs that consume it, so each group of MFMAs waited out an LDS round trip, and both
     // waves of a SIMD did so in step with each other).  A step's 8 + 2 MB fragment reads form one list --
@@ -259,7 +205,9 @@ __global__ __launch_bounds__(768, 3) void gemm_nt_rs_kernel(RsArgs g) {
     });
     static_for<4>([&](auto b) { P1[b.v] = rs_u32x4{0u, 0u, 0u, 0u}; });
     uint32_t a1, b1;
-    auto rd = [&P0, &P1, &Q, &a0, &a1, &b0, &b1](auto r) {          // read number r of the step's list
+    auto rd = [&P0, &P1, &Q, &a0, &a1, &b0, &b1](auto r) {          // read number r of the step's list (captures named: a
+        // generic lambda whose first instantiation leaves a branch out does not capture that branch's names by default)
+        (void)P0; (void)P1; (void)Q; (void)a0; (void)a1; (void)b0; (void)b1;
         constexpr int R = decltype(r)::v;
         if constexpr (R < 4) RS_DSR(P0[R], b0, R * 16 * ROWB);
         else if constexpr (R < 4 + MB) RS_DSR(Q[R - 4], a0, (R - 4) * 16 * ROWB);
@@ -267,6 +215,7 @@ __global__ __launch_bounds__(768, 3) void gemm_nt_rs_kernel(RsArgs g) {
         else RS_DSR(Q[R - 8 - MB], a1, (R - 8 - MB) * 16 * ROWB);
     };
     auto group = [&P0, &P1, &Q, &acc](auto g) {       // the four MFMAs of group g
+        (void)P0; (void)P1;
         constexpr int Gi = decltype(g)::v, A = Gi % MB;
         if constexpr (Gi < MB) {
             RS_MFMA(acc[A][0], P0[0], Q[A]); RS_MFMA(acc[A][1], P0[1], Q[A]);
@@ -281,6 +230,7 @@ __global__ __launch_bounds__(768, 3) void gemm_nt_rs_kernel(RsArgs g) {
         // vector instruction reads them
         auto& ar = acc;
         static_for<MB>([&ar](auto a) {
+            (void)ar;
             asm volatile("s_nop 15\n\ts_nop 15" : "+v"(ar[a.v][0]), "+v"(ar[a.v][1]), "+v"(ar[a.v][2]), "+v"(ar[a.v][3]));
         });
         // D[row = n][col = m]: lane = (m = li, q), register e -> n = 4 q + e.  (li, q re-derived here from an opaque
@@ -330,6 +280,7 @@ __global__ __launch_bounds__(768, 3) void gemm_nt_rs_kernel(RsArgs g) {
         }
         // ... and the fresh zeros theirs before the next MFMA takes them as its addend
         static_for<MB>([&ar](auto a) {
+            (void)ar;
             asm volatile("s_nop 7" : "+v"(ar[a.v][0]), "+v"(ar[a.v][1]), "+v"(ar[a.v][2]), "+v"(ar[a.v][3]));
         });
     };
@@ -342,19 +293,17 @@ __global__ __launch_bounds__(768, 3) void gemm_nt_rs_kernel(RsArgs g) {
             b1 = b0 ^ 64u;
             __builtin_amdgcn_s_barrier();    // B_step: this step's stages have landed, the previous step's are free
             asm volatile("" ::: "memory");
-            if (!SP_NT_LAB_NOMFMA) static_for<6>([&](auto r) { rd(r); });
+            static_for<6>([&](auto r) { rd(r); });
         }
-        if (!SP_NT_LAB_NOMFMA) {
-            group(IC<G - 2>{});              // the previous step's last two groups (zeros on the first pass)
-            group(IC<G - 1>{});
-        }
+        group(IC<G - 2>{});                  // the previous step's last two groups (zeros on the first pass)
+        group(IC<G - 1>{});
         if (ck == nk) {                      // ... which completed a tile
             epilogue(ctile);
             ck = 0;
             ctile += tl.nslots;
         }
         if (!more) break;
-        if (!SP_NT_LAB_NOMFMA) static_for<G - 2>([&](auto gi) {
+        static_for<G - 2>([&](auto gi) {
             constexpr int Gi = decltype(gi)::v;
             constexpr int issued = (6 + 2 * Gi < NRD) ? 6 + 2 * Gi : NRD;
             constexpr int need = Gi < MB ? 4 + Gi : 8 + Gi;
@@ -370,95 +319,6 @@ __global__ __launch_bounds__(768, 3) void gemm_nt_rs_kernel(RsArgs g) {
         stageB = stageB + 1 == NSTB ? 0 : stageB + 1;
         ++ck;
     }
-#else
-    const unsigned char* sa0 = smem + (wm * TM + li) * ROWB;
-    const unsigned char* sb0 = smem + BOFF + (wn * TN + li) * ROWB;
-    const int pc0 = ((0 + q) ^ swz) * 16, pc1 = ((4 + q) ^ swz) * 16;
-
-    rs_f32x4 acc[MB][NB];
-#pragma unroll
-    for (int a = 0; a < MB; ++a)
-#pragma unroll
-        for (int b = 0; b < NB; ++b) acc[a][b] = rs_f32x4{0.f, 0.f, 0.f, 0.f};
-
-    int ctile = tl.first, ck = 0, stageA = 0, stageB = 0;
-    for (int step = 0; step < total; ++step) {
-        __builtin_amdgcn_s_barrier();        // B_step
-        asm volatile("" ::: "memory");
-        const unsigned char* sa = sa0 + stageA * STA;
-        const unsigned char* sb = sb0 + stageB * STB;
-#pragma unroll
-        for (int kk = 0; kk < 2; ++kk) {
-            const int pc = kk ? pc1 : pc0;
-            rs_u32x4 P[NB];
-#pragma unroll
-            for (int b = 0; b < NB; ++b) P[b] = *reinterpret_cast<const rs_u32x4*>(sb + b * 16 * ROWB + pc);
-#pragma unroll
-            for (int a = 0; a < MB; ++a) {
-                const rs_u32x4 Q = *reinterpret_cast<const rs_u32x4*>(sa + a * 16 * ROWB + pc);
-#pragma unroll
-                for (int b = 0; b < NB; ++b) {
-                    if constexpr (IN == SP_F16)
-                        acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(rs_f16x8, P[b]),
-                                                                           __builtin_bit_cast(rs_f16x8, Q), acc[a][b], 0, 0, 0);
-                    else
-                        acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(rs_bf16x8, P[b]),
-                                                                            __builtin_bit_cast(rs_bf16x8, Q), acc[a][b], 0, 0, 0);
-                }
-            }
-        }
-        asm volatile("" ::: "memory");
-        stageA = stageA + 1 == NSTA ? 0 : stageA + 1;
-        stageB = stageB + 1 == NSTB ? 0 : stageB + 1;
-        if (++ck == nk) {
-            // D[row = n][col = m]: lane = (m = li, q), register e -> n = 4 q + e
-            const int m0 = tl.tile_m(ctile) * BM + wm * TM, n0 = tl.tile_n(ctile) * BN + wn * TN;
-#pragma unroll
-            for (int a = 0; a < MB; ++a) {
-                const int m = m0 + a * 16 + li;
-                if constexpr (OUT == SP_F32) {
-                    float* crow = reinterpret_cast<float*>(g.C) + (int64_t)m * g.ldc + n0 + 4 * q;
-                    if (m < g.M) {
-#pragma unroll
-                        for (int b = 0; b < NB; ++b) *reinterpret_cast<rs_f32x4*>(crow + b * 16) = acc[a][b];
-                    }
-                } else {
-                    auto pk = [](float lo, float hi) {
-                        if constexpr (IN == SP_F16)
-                            return (uint32_t)__builtin_bit_cast(unsigned short, __float2half(lo)) |
-                                   ((uint32_t)__builtin_bit_cast(unsigned short, __float2half(hi)) << 16);
-                        else
-                            return (uint32_t)__builtin_bit_cast(unsigned short, __float2bfloat16(lo)) |
-                                   ((uint32_t)__builtin_bit_cast(unsigned short, __float2bfloat16(hi)) << 16);
-                    };
-                    // rows (16-lane groups) 1 and 3 of x trade places with rows 0 and 2 of y: every lane then holds 8
-                    // consecutive n: columns 16 b + (q & 1) * 16 + (q >> 1) * 8 of its row
-                    rs_u32x4 o[NB / 2];
-#pragma unroll
-                    for (int b = 0; b < NB; b += 2) {
-                        const uint32_t x0 = pk(acc[a][b][0], acc[a][b][1]), x1 = pk(acc[a][b][2], acc[a][b][3]);
-                        const uint32_t y0 = pk(acc[a][b + 1][0], acc[a][b + 1][1]), y1 = pk(acc[a][b + 1][2], acc[a][b + 1][3]);
-                        const auto s0 = __builtin_amdgcn_permlane16_swap(x0, y0, false, false);
-                        const auto s1 = __builtin_amdgcn_permlane16_swap(x1, y1, false, false);
-                        o[b / 2] = rs_u32x4{s0[0], s1[0], s0[1], s1[1]};
-                    }
-                    const int cq = (q & 1) * 16 + (q >> 1) * 8;
-                    {
-                        __hip_bfloat16* crow = reinterpret_cast<__hip_bfloat16*>(g.C) + (int64_t)m * g.ldc + n0 + cq;
-#pragma unroll
-                        for (int b = 0; b < NB; b += 2) {
-                            if (m < g.M) *reinterpret_cast<rs_u32x4*>(crow + b * 16) = o[b / 2];
-                        }
-                    }
-                }
-#pragma unroll
-                for (int b = 0; b < NB; ++b) acc[a][b] = rs_f32x4{0.f, 0.f, 0.f, 0.f};
-            }
-            ck = 0;
-            ctile += tl.nslots;
-        }
-    }
-#endif
 }
 
 template <int BM, int BN, int WMW, int NSTA>

@@ -322,6 +322,7 @@ def comm_profile(dp, opt, step, args, world, ms_step_dp):
     every bucket's all-reduce alone (HIP events on the launch stream around a blocking collective, median of 5),
     and the step without any exchange (each rank stepping on its own gradients).  exposed = step with the exchange
     - step without; overlap_frac = the share of the stand-alone all-reduce time that backward hid."""
+    from speech_amd.train import all_reduce_sum
     per_bucket = []
     for lo, hi, _ in dp.buckets:
         view = opt.flat_grad[lo:hi]
@@ -329,7 +330,7 @@ def comm_profile(dp, opt, step, args, world, ms_step_dp):
         for _r in range(5):
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             e0.record()
-            dist.all_reduce(view, group=dp.group)
+            all_reduce_sum(view, dp.group)
             e1.record()
             torch.cuda.synchronize()
             ts.append(e0.elapsed_time(e1))
@@ -351,7 +352,7 @@ def comm_profile(dp, opt, step, args, world, ms_step_dp):
     finally:
         dp._launch, dp.finish = launch, finish
     tm = torch.tensor([ms_nocomm], dtype=torch.float64, device=opt.flat_grad.device)
-    dist.all_reduce(tm, op=dist.ReduceOp.MAX)
+    all_reduce_sum(tm, dp.group, dist.ReduceOp.MAX)
     ms_nocomm = float(tm.item())
     total = sum(per_bucket)
     exposed = max(ms_step_dp - ms_nocomm, 0.0)
@@ -362,25 +363,80 @@ def comm_profile(dp, opt, step, args, world, ms_step_dp):
             "backend": dist.get_backend(dp.group)}
 
 
-def spawn_ranks(n):
+def spawn_ranks(n, deadline_s=None, log_dir=None, cmd=None):
     """`python bench.py --gpus N` typed as is: start N fresh rank processes of this script (one per GPU, the
     launcher's environment contract: RANK / LOCAL_RANK / WORLD_SIZE / MASTER_ADDR / MASTER_PORT) and relay rank 0's
-    JSON line.  Nothing in this process has touched the GPU, and nothing is exec'ed: the ranks are children."""
+    JSON line.  Nothing in this process has touched the GPU, and nothing is exec'ed: the ranks are children.
+    Fails fast: the children are polled; the first one that exits non-zero (a rank that dies at RCCL init leaves the
+    others blocked in a collective) ends the rest, and so does the overall deadline (BENCH_DEADLINE_S, default 540 s:
+    below the driver's limit, so that a line about the failure still gets out).  Every rank's stderr goes to its own
+    file (BENCH_LOG_DIR, default gpurun_out/ or the temp dir) and the failing rank's tail is printed.
+    cmd: the rank command line (default: this script with this process's arguments; the launcher's test passes its own)."""
+    import signal
     import socket
     import subprocess
+    import tempfile
+    deadline_s = float(os.environ.get("BENCH_DEADLINE_S", "540")) if deadline_s is None else deadline_s
+    log_dir = log_dir or os.environ.get("BENCH_LOG_DIR") or (
+        os.path.join(ROOT, "gpurun_out") if os.path.isdir(os.path.join(ROOT, "gpurun_out")) else tempfile.gettempdir())
     with socket.socket() as sk:
         sk.bind(("127.0.0.1", 0))
         port = sk.getsockname()[1]
-    procs = []
+    procs, logs = [], []
     for r in range(n):
         env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), MASTER_ADDR="127.0.0.1",
                    MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
-        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
-                                      stdout=None if r == 0 else subprocess.DEVNULL))
-    rc = 0
-    for p in procs:
-        rc = p.wait() or rc
-    return rc
+        path = os.path.join(log_dir, f"bench_rank{r}.stderr")
+        logs.append(path)
+        with open(path, "wb") as err:
+            procs.append(subprocess.Popen(cmd or ([sys.executable, os.path.abspath(__file__)] + sys.argv[1:]), env=env,
+                                          stdout=None if r == 0 else subprocess.DEVNULL, stderr=err,
+                                          start_new_session=True))      # its own process group: ended as a whole
+
+    def end_all():
+        for q in procs:
+            if q.poll() is None:
+                try:
+                    os.killpg(q.pid, signal.SIGTERM)
+                except ProcessLookupError:
+                    pass
+        t_end = time.time() + 5.0
+        for q in procs:
+            try:
+                q.wait(timeout=max(0.1, t_end - time.time()))
+            except subprocess.TimeoutExpired:
+                try:
+                    os.killpg(q.pid, signal.SIGKILL)
+                except ProcessLookupError:
+                    pass
+                q.wait()
+
+    t0, rc, why = time.time(), 0, None
+    try:
+        while True:
+            codes = [q.poll() for q in procs]
+            bad = [(r, c) for r, c in enumerate(codes) if c not in (None, 0)]
+            if bad:
+                rc, why = bad[0][1], f"rank {bad[0][0]} exited with code {bad[0][1]}"
+                break
+            if all(c == 0 for c in codes):
+                break
+            if time.time() - t0 > deadline_s:
+                rc, why = 124, f"deadline of {deadline_s:.0f} s passed with ranks {[r for r, c in enumerate(codes) if c is None]} still running"
+                break
+            time.sleep(0.05)
+    finally:
+        end_all()
+    if why:
+        sys.stderr.write(f"bench.py: {why}; the other ranks were terminated\n")
+        for r, path in enumerate(logs):
+            try:
+                tail = open(path, "rb").read()[-1500:].decode("utf-8", "replace")
+            except OSError:
+                tail = ""
+            if tail.strip():
+                sys.stderr.write(f"--- rank {r} stderr (tail of {path}) ---\n{tail}\n")
+    return rc if rc else 0
 
 
 def main():
@@ -442,7 +498,8 @@ def main():
     dt = time.perf_counter() - t0
     tmax = torch.tensor([dt], dtype=torch.float64, device=dev)
     if world > 1:
-        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        from speech_amd.train import all_reduce_sum
+        all_reduce_sum(tmax, None, dist.ReduceOp.MAX)
     dt = float(tmax.item())
     loss_val = float(loss)
 

@@ -81,8 +81,8 @@ int sp_melspec_fwd(const void* wav, const int64_t* wav_offsets, int B, int T_max
  * labels (the caller, who knows the lengths on the host, is expected to pass a true bound).
  * Outputs: nll[B] (per-utterance negative log likelihood, +inf if infeasible), loss[1] =
  * mean_b nll_b / max(L_b,1), grad (may be NULL) laid out like logits =
- * grad_scale * d loss / d logits, of grad_dtype SP_F32 or SP_BF16 (same strides in elements; bf16
- * when the consumer is a bf16 GEMM: its rounding happens in the store); frames t >=
+ * grad_scale * d loss / d logits, of grad_dtype SP_F32, SP_BF16 or SP_F16 (same strides in elements; a
+ * 16-bit type when the consumer is a GEMM of that type: its rounding happens in the store); frames t >=
  * input_lengths[b] get 0.
  * Range: the lattice runs on scaled f64 probabilities, not in log space.  It agrees with torch's float64 CTC to
  * 1e-7 on scores as sharp as a mean loss of 45 bits (31 nats) per frame (tests/test_gpu_kernels.py

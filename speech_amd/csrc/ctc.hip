@@ -528,6 +528,15 @@ __device__ __forceinline__ void store4(__hip_bfloat16* g, int c, float a, float 
     reinterpret_cast<uint2*>(g)[c] = o;
 }
 
+__device__ __forceinline__ void store4(__half* g, int c, float a, float b, float x, float y) {
+    uint2 o;
+    o.x = (uint32_t)__builtin_bit_cast(unsigned short, __float2half(a)) |
+          ((uint32_t)__builtin_bit_cast(unsigned short, __float2half(b)) << 16);
+    o.y = (uint32_t)__builtin_bit_cast(unsigned short, __float2half(x)) |
+          ((uint32_t)__builtin_bit_cast(unsigned short, __float2half(y)) << 16);
+    reinterpret_cast<uint2*>(g)[c] = o;
+}
+
 // The DENSE half of the gradient: softmax(z) * scale over the whole vocabulary, zero rows beyond an utterance's
 // length.  It needs K1's log-sum-exp only, so it does not wait for the lattice: the workgroups behind the 2B lattice
 // workgroups of ctc_lattice1_kernel's grid run it on the CUs (and the memory bandwidth) the lattice leaves idle.
@@ -633,8 +642,11 @@ __global__ __launch_bounds__(kLat1Threads) void ctc_lattice1_kernel(
     if ((int)blockIdx.x >= 2 * B) {
         constexpr int nw = kLat1Threads / 64;
         const int id = ((int)blockIdx.x - 2 * B) * nw + (int)(threadIdx.x >> 6), n = ((int)gridDim.x - 2 * B) * nw;
-        if (grad_bf16)
+        if (grad_bf16 == 1)
             ctc_dense_rows(logits, st, sb, in_len, lab_len, T, B, V, Lmax, lse2, grad_scale, (__hip_bfloat16*)grad, id, n,
+                           (int)(threadIdx.x & 63));
+        else if (grad_bf16 == 2)
+            ctc_dense_rows(logits, st, sb, in_len, lab_len, T, B, V, Lmax, lse2, grad_scale, (__half*)grad, id, n,
                            (int)(threadIdx.x & 63));
         else
             ctc_dense_rows(logits, st, sb, in_len, lab_len, T, B, V, Lmax, lse2, grad_scale, (float*)grad, id, n,
@@ -1177,7 +1189,8 @@ extern "C" int sp_ctc_fwd_bwd(const float* logits, int64_t stride_t, int64_t str
                               int max_label_len, float grad_scale, float* nll, float* loss,
                               void* grad, int grad_dtype, void* workspace, size_t workspace_bytes, void* stream) {
     using namespace sp;
-    SP_CHECK_ARG(!grad || grad_dtype == SP_F32 || grad_dtype == SP_BF16, "sp_ctc_fwd_bwd: grad_dtype %d", grad_dtype);
+    SP_CHECK_ARG(!grad || grad_dtype == SP_F32 || grad_dtype == SP_BF16 || grad_dtype == SP_F16,
+                 "sp_ctc_fwd_bwd: grad_dtype %d", grad_dtype);
     SP_CHECK_ARG(T >= 0 && B >= 0 && V >= 1, "sp_ctc_fwd_bwd: bad shape T=%d B=%d V=%d", T, B, V);
     SP_CHECK_ARG(V <= kMaxV, "sp_ctc_fwd_bwd: V=%d exceeds the supported maximum %d", V, kMaxV);
     SP_CHECK_ARG(blank >= 0 && blank < V, "sp_ctc_fwd_bwd: blank %d outside [0,%d)", blank, V);
@@ -1229,7 +1242,7 @@ extern "C" int sp_ctc_fwd_bwd(const float* logits, int64_t stride_t, int64_t str
     // sized this way: the generic one (odd or large V) is latency-bound per wave and takes every free CU.
     int dense_blocks = split ? kCUs - 2 * B : 0;
     if (split && V % 4 == 0 && V <= 1024) {
-        const double bytes = (double)T * B * V * (4 + (grad_dtype == SP_BF16 ? 2 : 4));
+        const double bytes = (double)T * B * V * (4 + (grad_dtype == SP_F32 ? 4 : 2));
         const double t_lat = (double)T * (S <= 128 ? 52e-9 : S <= 256 ? 76e-9 : 125e-9);
         const double per_cu = bytes > 200e6 ? 22e9 : 32e9;
         dense_blocks = std::min(dense_blocks, std::max(32, (int)(1.3 * bytes / (t_lat * per_cu)) + 1));
@@ -1237,7 +1250,7 @@ extern "C" int sp_ctc_fwd_bwd(const float* logits, int64_t stride_t, int64_t str
 #define SP_LAT1_ARGS ws + d.off_rows, labels, label_stride, input_lengths, label_lengths, T, V, blank, max_label_len, d.RW, \
                      d.SP, d.modeB, dblw, dblw + (size_t)B * T * d.SP, reinterpret_cast<double*>(ws + d.off_aux),           \
                      dblw + (size_t)2 * B * T * d.SP, nll, B, logits, stride_t, stride_b, ws + d.off_lse, grad_scale, grad,  \
-                     grad_dtype == SP_BF16 ? 1 : 0
+                     grad_dtype == SP_BF16 ? 1 : (grad_dtype == SP_F16 ? 2 : 0)
 #define SP_LAT1(NS, H)                                                                                                       \
     hipLaunchKernelGGL((ctc_lattice1_kernel<NS, H>), dim3(2 * B + dense_blocks), dim3(split ? kLat1Threads : 64 * (1 + H)),  \
                        split ? kLat1DynLds : 0, s, SP_LAT1_ARGS)
@@ -1272,6 +1285,9 @@ extern "C" int sp_ctc_fwd_bwd(const float* logits, int64_t stride_t, int64_t str
         if (grad_dtype == SP_BF16)                                                                                           \
             hipLaunchKernelGGL((ctc_sparse_kernel<__hip_bfloat16, NI, R>), dim3(sg), dim3(256), sl, s, SP_GRAD_ARGS,         \
                                (__hip_bfloat16*)grad, loss, d.perm);                                                                 \
+        else if (grad_dtype == SP_F16)                                                                                       \
+            hipLaunchKernelGGL((ctc_sparse_kernel<__half, NI, R>), dim3(sg), dim3(256), sl, s, SP_GRAD_ARGS,                 \
+                               (__half*)grad, loss, d.perm);                                                                 \
         else                                                                                                                 \
             hipLaunchKernelGGL((ctc_sparse_kernel<float, NI, R>), dim3(sg), dim3(256), sl, s, SP_GRAD_ARGS, (float*)grad,    \
                                loss, d.perm);                                                                                     \
@@ -1288,6 +1304,9 @@ extern "C" int sp_ctc_fwd_bwd(const float* logits, int64_t stride_t, int64_t str
             if (grad && grad_dtype == SP_BF16)
                 hipLaunchKernelGGL((ctc_grad_kernel<__hip_bfloat16>), dim3(gb), dim3(256), lds, s, SP_GRAD_ARGS,
                                    T > 0 ? (__hip_bfloat16*)grad : nullptr, loss, d.perm);
+            else if (grad && grad_dtype == SP_F16)
+                hipLaunchKernelGGL((ctc_grad_kernel<__half>), dim3(gb), dim3(256), lds, s, SP_GRAD_ARGS,
+                                   T > 0 ? (__half*)grad : nullptr, loss, d.perm);
             else
                 hipLaunchKernelGGL((ctc_grad_kernel<float>), dim3(gb), dim3(256), lds, s, SP_GRAD_ARGS,
                                    T > 0 ? (float*)grad : nullptr, loss, d.perm);

@@ -139,8 +139,8 @@ def ctc_fwd_bwd(logits, labels, input_lengths, label_lengths, blank=0, max_label
     loss = mean_b nll_b / max(L_b, 1) of log_softmax(logits); grad = grad_scale * dloss/dlogits, stored as
     grad_dtype (float32, or bfloat16 for a bf16 consumer: rounded once, in the kernel's store).
     """
-    if grad_dtype not in (torch.float32, torch.bfloat16):
-        raise ValueError("grad_dtype must be float32 or bfloat16")
+    if grad_dtype not in (torch.float32, torch.bfloat16, torch.float16):
+        raise ValueError("grad_dtype must be float32, bfloat16 or float16")
     _need_cuda(logits, "logits")
     if logits.dtype != torch.float32:
         raise ValueError("logits must be float32 (the reference computes CTC in fp32)")
@@ -160,15 +160,17 @@ def ctc_fwd_bwd(logits, labels, input_lengths, label_lengths, blank=0, max_label
         labels = labels.contiguous()
     if labels.numel() == 0:
         labels = torch.zeros((B, 1), dtype=torch.int64, device=dev)
-    input_lengths = input_lengths.to(device=dev, dtype=torch.int32).contiguous()
-    label_lengths = label_lengths.to(device=dev, dtype=torch.int32).contiguous()
     if max_label_len is None:
         max_label_len = int(labels.shape[1])
         if max_label_len > 1023:
             raise ValueError(f"labels are padded to {max_label_len} > 1023 columns: pass max_label_len (<= 1023), "
                              "a true bound on label_lengths")
+    # lengths that are still on the host can be checked without a device round trip (device lengths are clamped by
+    # the kernel, as the header says)
     if not label_lengths.is_cuda and label_lengths.numel() and int(label_lengths.max()) > max_label_len:
         raise ValueError(f"label_lengths.max() = {int(label_lengths.max())} exceeds max_label_len = {max_label_len}")
+    input_lengths = input_lengths.to(device=dev, dtype=torch.int32).contiguous()
+    label_lengths = label_lengths.to(device=dev, dtype=torch.int32).contiguous()
     nll = torch.empty(B, dtype=torch.float32, device=dev)
     loss = torch.empty(1, dtype=torch.float32, device=dev)
     if grad_out is not None:      # caller-owned gradient buffer, same strides (in elements) as the logits

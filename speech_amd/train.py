@@ -58,24 +58,30 @@ class FlatAdam(torch.optim.Optimizer):
     contiguous buffers (16-byte aligned slices), so the global grad norm, the clip and the update
     are two kernel launches, and gradient buckets for the all-reduce are plain slices.
     state_bits = 8 keeps the moments as bitsandbytes-style block-wise 8-bit codes (train.py:254 Adam8bit;
-    blocks of 2048 elements of the flat arena, one absmax per block and moment): 2 bytes of state per
-    parameter instead of 8, and 16 instead of 28 bytes of traffic per parameter and step."""
+    blocks of 2048 elements, one absmax per block and moment, every parameter aligned to a block boundary so
+    that no block spans two tensors): 2 bytes of state per parameter instead of 8, and 16 instead of 28 bytes
+    of traffic per parameter and step.  One stated difference to bitsandbytes is left: it keeps 32-bit moments
+    for tensors below 4096 elements (biases, LayerNorm / BatchNorm vectors, weight_c); here those are quantised
+    too, each in blocks of its own."""
 
     def __init__(self, params, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.0,
                  decoupled_weight_decay=True, state_bits=32):
         params = [p for p in params if p.requires_grad]
         super().__init__(params, dict(lr=lr, betas=betas, eps=eps, weight_decay=weight_decay))
+        if state_bits not in (8, 32):
+            raise ValueError("state_bits must be 32 or 8")
         self.plist = params
         dev = params[0].device
+        # 8-bit state: every parameter starts on a quantisation-block boundary, so that no block (one absmax per
+        # 2048 elements and moment) spans two tensors -- bitsandbytes quantises each tensor on its own
+        align = ADAM8_BLOCK if state_bits == 8 else 4
         self.offsets, total = [], 0
         for p in params:
             self.offsets.append(total)
-            total += (p.numel() + 3) // 4 * 4
+            total += (p.numel() + align - 1) // align * align
         self.total = total
         self.flat = torch.zeros(total, dtype=torch.float32, device=dev)
         self.flat_grad = torch.zeros(total, dtype=torch.float32, device=dev)
-        if state_bits not in (8, 32):
-            raise ValueError("state_bits must be 32 or 8")
         self.state_bits = state_bits
         if state_bits == 32:
             self.exp_avg = torch.zeros(total, dtype=torch.float32, device=dev)
@@ -143,20 +149,54 @@ class FlatAdam(torch.optim.Optimizer):
             self.absmax2.copy_(sd["absmax2"])
 
 
+def _host_staged(group, t):
+    """gloo never sees a device tensor here (see BucketedAllReduce)."""
+    return dist.get_backend(group) == "gloo" and t.is_cuda
+
+
+def all_reduce_sum(t, group=None, op=None):
+    """Blocking all-reduce of `t` in place on either backend: RCCL takes the device tensor; gloo gets a host copy."""
+    op = dist.ReduceOp.SUM if op is None else op
+    if _host_staged(group, t):
+        h = t.detach().cpu()
+        dist.all_reduce(h, op=op, group=group)
+        t.copy_(h)
+    else:
+        dist.all_reduce(t, op=op, group=group)
+    return t
+
+
+def broadcast_(t, src=0, group=None):
+    if _host_staged(group, t):
+        h = t.detach().cpu()
+        dist.broadcast(h, src=src, group=group)
+        t.copy_(h)
+    else:
+        dist.broadcast(t, src=src, group=group)
+    return t
+
+
 class BucketedAllReduce:
     """Data-parallel gradient exchange: the flat gradient arena is cut, from its END (the
     classifier and the last SRU layers, whose gradients are ready first), into buckets of about
     ``bucket_mb``; a post-accumulate hook on every parameter counts its bucket down and the bucket's
     all-reduce (sum; the mean's 1/world is folded into the optimizer's grad_div) is launched
-    asynchronously on RCCL as soon as the bucket is complete, overlapping the rest of backward."""
+    asynchronously on RCCL as soon as the bucket is complete, overlapping the rest of backward.
+
+    RCCL: the collective is enqueued on RCCL's own stream behind an event on the launch stream; the host never
+    waits (`finish` makes the launch stream wait on the collectives' events), so a bucket may be launched from the
+    autograd thread in the middle of backward.
+    gloo (CPU tests; the two-ranks-on-one-card rehearsal): device tensors are NOT handed to ProcessGroupGloo.  Its
+    device-tensor path stages through pinned memory on side streams and runs `hipStreamSynchronize` and copies from
+    its own worker threads while the autograd thread is still launching backward kernels; round 2's intermittent
+    two-rank hang sat in exactly that combination.  A completed bucket is therefore only RECORDED
+    during backward (same hook logic, same order) and exchanged in `finish`, on the calling thread, through a host
+    buffer: no foreign thread touches the HIP runtime and every rank enters the collectives in the recorded order."""
 
     def __init__(self, opt, group=None, bucket_mb=25.0):
         self.opt, self.group = opt, group
         self.world = dist.get_world_size(group)
-        # gloo (CPU tests, two ranks on one card) stages device tensors through the host on streams of its own;
-        # draining the launch stream first keeps that path to plain synchronous copies.  RCCL stays fully
-        # asynchronous.
-        self.drain = dist.get_backend(group) == "gloo" and opt.flat_grad.is_cuda
+        self.host_staged = _host_staged(group, opt.flat_grad)
         cap = int(bucket_mb * 1024 * 1024 / 4)
         self.buckets = []   # [lo, hi, n_params]
         self.bucket_of = {}
@@ -170,6 +210,7 @@ class BucketedAllReduce:
                 hi, count = lo, 0
         self.pending = [b[2] for b in self.buckets]
         self.handles = []
+        self.order = []          # buckets in the order they were launched this step (the same on every rank)
         self.done = set()
         self.hooks = [self._make_hook(idx) for idx in range(len(opt.plist))]
         # keyed by storage address: inside autograd functions a parameter may arrive as another Python
@@ -177,8 +218,10 @@ class BucketedAllReduce:
         self.index_of = {p.data_ptr(): idx for idx, p in enumerate(opt.plist)}
         for idx, p in enumerate(opt.plist):
             p.register_post_accumulate_grad_hook(self.hooks[idx])
+        if self.host_staged:
+            self.stage = torch.empty(max(hi - lo for lo, hi, _ in self.buckets), dtype=torch.float32).pin_memory()
         # start from identical replicas
-        dist.broadcast(opt.flat, src=0, group=group)
+        broadcast_(opt.flat, 0, group)
 
     def _make_hook(self, idx):
         def hook(_param):
@@ -194,9 +237,10 @@ class BucketedAllReduce:
         return hook
 
     def _launch(self, b):
+        self.order.append(b)
+        if self.host_staged:
+            return           # exchanged in finish(), in this order
         lo, hi, _ = self.buckets[b]
-        if self.drain:
-            torch.cuda.current_stream().synchronize()
         self.handles.append(dist.all_reduce(self.opt.flat_grad[lo:hi], group=self.group, async_op=True))
 
     def param_ready(self, p):
@@ -211,9 +255,17 @@ class BucketedAllReduce:
         for b, left in enumerate(self.pending):
             if left > 0:
                 self._launch(b)
+        if self.host_staged:
+            for b in self.order:
+                lo, hi, _ = self.buckets[b]
+                h = self.stage[:hi - lo]
+                h.copy_(self.opt.flat_grad[lo:hi])        # blocking: the launch stream has produced the bucket
+                dist.all_reduce(h, group=self.group)
+                self.opt.flat_grad[lo:hi].copy_(h)
         for h in self.handles:
             h.wait()
         self.handles = []
+        self.order = []
         self.done = set()
         self.pending = [b[2] for b in self.buckets]
 
@@ -271,11 +323,11 @@ def train(batch_size, model, train_loader, optimizer, scheduler, epoch, iter_met
 
 
 @torch.no_grad()
-def eval_dataset(model, loader, name, log=print, dtype=torch.float32):
+def eval_dataset(model, loader, name, log=print, dtype=torch.float32, group=None, world=1):
     """train.py:105-144: mean loss, unweighted mean of per-utterance CER / WER.  The reference evaluates
-    outside autocast, i.e. in fp32 (train.py:162-168): `dtype` is the activation type of the SRU stack and
-    the classifier for this pass (None = the model's training type; the conv stack's kernels keep bf16
-    activations either way)."""
+    outside autocast, i.e. in fp32 (train.py:162-168): `dtype` is the activation type for this pass (None = the
+    model's training type).  world > 1: every rank evaluates its own share of the loader (build_loaders shards
+    them) and the sums are all-reduced, so no rank sits in a collective while another one evaluates alone."""
     model.eval()
     saved = getattr(model, "compute_dtype", None)
     if dtype is not None and saved is not None:
@@ -298,17 +350,40 @@ def eval_dataset(model, loader, name, log=print, dtype=torch.float32):
     finally:
         if saved is not None:
             model.compute_dtype = saved
-    avg_cer = sum(eval_cer) / len(eval_cer)
-    avg_wer = sum(eval_wer) / len(eval_wer)
+    sums = torch.tensor([eval_loss, float(n), sum(eval_cer), sum(eval_wer), float(len(eval_cer))], dtype=torch.float64)
+    if world > 1:
+        sums = all_reduce_sum(sums.cuda() if torch.cuda.is_available() else sums, group).cpu()
+    eval_loss, n, cer_sum, wer_sum, n_utt = (float(v) for v in sums)
+    avg_cer = cer_sum / n_utt
+    avg_wer = wer_sum / n_utt
     log("{}: Average loss: {:.4f}, Average CER: {:4f} Average WER: {:.4f}\n".format(
-        name, eval_loss / max(1, n), avg_cer, avg_wer))
+        name, eval_loss / max(1.0, n), avg_cer, avg_wer))
     return avg_cer
 
 
-def save_checkpoint(path, epoch, model, optimizer):
-    """train.py:171-178 key names."""
-    torch.save({"epoch": epoch, "model_state_dict": model.state_dict(),
-                "optimizer_state_dict": optimizer.state_dict()}, path)
+def save_checkpoint(path, epoch, model, optimizer, iterations=None):
+    """train.py:171-178 key names (+ the scheduler's step count, which the reference's commented-out resume
+    would have needed too)."""
+    ck = {"epoch": epoch, "model_state_dict": model.state_dict(), "optimizer_state_dict": optimizer.state_dict()}
+    if iterations is not None:
+        ck["iterations"] = int(iterations)
+    torch.save(ck, path)
+
+
+def resume_from(path, model, optimizer=None, map_location="cuda"):
+    """Load a checkpoint in either shape the reference writes.  With the full dict of save_checkpoint the
+    optimizer's moments / step count come back too (train.py:249-260's resume stub loads both); returns
+    (epoch, iterations) to continue from, (0, 0) for a bare state_dict."""
+    ck = torch.load(path, map_location=map_location, weights_only=True)
+    model.load_checkpoint(ck)
+    epoch = iterations = 0
+    if isinstance(ck, dict) and "model_state_dict" in ck:
+        epoch = int(ck.get("epoch", 0))
+        iterations = int(ck.get("iterations", 0))
+        osd = ck.get("optimizer_state_dict")
+        if optimizer is not None and osd is not None and hasattr(optimizer, "load_state_dict") and "exp_avg" in osd:
+            optimizer.load_state_dict(osd)       # raises if the state widths differ (8-bit vs fp32)
+    return epoch, iterations
 
 
 def setup_distributed():
@@ -319,7 +394,11 @@ def setup_distributed():
         torch.cuda.set_device(local)
     if world > 1 and not dist.is_initialized():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl" if torch.cuda.is_available() else "gloo")
+        import datetime
+        # ranks only ever wait for each other inside a step's exchange or the end-of-epoch sums (evaluation is
+        # sharded), so a rank that stops answering for this long has died
+        dist.init_process_group("nccl" if torch.cuda.is_available() else "gloo",
+                                timeout=datetime.timedelta(minutes=int(os.environ.get("SP_DIST_TIMEOUT_MIN", "30"))))
     return int(os.environ.get("RANK", "0")), world
 
 
@@ -358,6 +437,23 @@ class RankBatchSampler(torch.utils.data.Sampler):
         else:
             order = list(range(self.n))
         return iter(order[self.rank:len(self) * self.world:self.world])
+
+
+class ShardSampler(torch.utils.data.Sampler):
+    """Evaluation share of one rank: indices rank, rank + world, ... of an optional permutation every rank derives
+    from the same seed.  Nothing is dropped or repeated (ranks may differ by one item: no collective runs inside an
+    evaluation pass, the sums are exchanged once at its end)."""
+
+    def __init__(self, n, rank=0, world=1, shuffle=False, seed=11):
+        self.n, self.rank, self.world, self.shuffle, self.seed = n, rank, world, shuffle, seed
+
+    def __len__(self):
+        return len(range(self.rank, self.n, self.world))
+
+    def __iter__(self):
+        order = (torch.randperm(self.n, generator=torch.Generator().manual_seed(self.seed)).tolist()
+                 if self.shuffle else list(range(self.n)))
+        return iter(order[self.rank::self.world])
 
 
 class FeaturizingLoader:
@@ -409,12 +505,15 @@ def build_loaders(hparams, rank, world):
         sampler.n = min(sampler.n, hparams["steps"] * world)
     train_loader = FeaturizingLoader(torch.utils.data.DataLoader(
         train_set, batch_size=None, sampler=sampler, collate_fn=_clips, num_workers=workers, pin_memory=False), "train")
+    # train.py:222-239: the tv evaluation walks its batches shuffled, the ibm one in order; each rank takes every
+    # world-th batch / utterance (world 1: exactly the reference's loaders)
     evals = [("tv", FeaturizingLoader(torch.utils.data.DataLoader(
-        tv_eval, batch_size=None, shuffle=True, collate_fn=_clips, num_workers=min(workers, 4)), "valid"))]
+        tv_eval, batch_size=None, sampler=ShardSampler(len(tv_eval), rank, world, shuffle=True), collate_fn=_clips,
+        num_workers=min(workers, 4)), "valid"))]
     if ibm_eval is not None:
         evals.append(("ibm", FeaturizingLoader(torch.utils.data.DataLoader(
-            ibm_eval, batch_size=32 * hparams["multiplier"] * 2, shuffle=False, collate_fn=_clips,
-            num_workers=min(workers, 4)), "valid")))
+            ibm_eval, batch_size=32 * hparams["multiplier"] * 2, sampler=ShardSampler(len(ibm_eval), rank, world),
+            collate_fn=_clips, num_workers=min(workers, 4)), "valid")))
     return train_loader, sampler, evals
 
 
@@ -425,32 +524,39 @@ def main(hparams):
     dtype = {"bf16": torch.bfloat16, "fp16": torch.float16, "fp32": torch.float32}[hparams["dtype"]]
     model = net.SRModel(hparams["n_rnn_layers"], hparams["rnn_dim"], hparams["n_vocab"], hparams["n_feats"],
                         hparams["dropout"], hparams["projection_size"], compute_dtype=dtype).cuda()
-    if hparams.get("resume"):
-        model.load_checkpoint(torch.load(hparams["resume"], map_location="cuda", weights_only=True))
     log("Num Model Parameters", sum(p.nelement() for p in model.parameters()))
     optimizer = FlatAdam(model.parameters(), lr=hparams["learning_rate"], weight_decay=hparams["weight_decay"],
                          state_bits=hparams.get("optim_bits", 32))
+    start_epoch = start_iter = 0
+    if hparams.get("resume"):      # weights, and with a full checkpoint the optimizer state, epoch and step count
+        start_epoch, start_iter = resume_from(hparams["resume"], model, optimizer)
     dp = BucketedAllReduce(optimizer) if world > 1 else None
 
     train_loader, sampler, evals = build_loaders(hparams, rank, world)
     scheduler = get_linear_schedule_with_warmup(optimizer, 7000 // hparams["multiplier"],
                                                 hparams["epochs"] * len(train_loader))
     iter_meter, last_cer = IterMeter(), 2.0
+    if start_iter:                 # a resumed run continues the warm-up / decay where the checkpoint left it
+        import warnings
+        with warnings.catch_warnings():
+            warnings.simplefilter("ignore")
+            scheduler.step(start_iter)
+        iter_meter.val = start_iter
     eval_dtype = {"fp32": torch.float32, "same": None}[hparams.get("eval_dtype", "fp32")]
-    for epoch in range(1, (1 if hparams["one_iter"] else hparams["epochs"]) + 1):
+    for epoch in range(start_epoch + 1, (1 if hparams["one_iter"] else hparams["epochs"]) + 1):
         sampler.set_epoch(epoch)
         train(hparams["batch_size"], model, train_loader, optimizer, scheduler, epoch, iter_meter,
               hparams["clip_grad_norm"], dp, log=log)
-        if rank == 0:     # train.py:147-179: the last evaluation's CER (ibm when present) picks the checkpoint
-            log("\nevaluating...")
-            for name, loader in evals:
-                avg_cer = eval_dataset(model, loader, name, log, eval_dtype)
-            if avg_cer < last_cer and hparams["checkpoint"]:
-                save_checkpoint(hparams["checkpoint"], epoch, model, optimizer)
-            last_cer = avg_cer
-        if world > 1:     # the other ranks wait here, not inside the next epoch's first all-reduce
-            dist.barrier()
+        # train.py:147-179: the last evaluation's CER (ibm when present) picks the checkpoint.  Every rank evaluates
+        # its share and the sums are all-reduced: no rank waits in a collective while another evaluates alone.
+        log("\nevaluating...")
+        for name, loader in evals:
+            avg_cer = eval_dataset(model, loader, name, log, eval_dtype, None, world)
+        if rank == 0 and avg_cer < last_cer and hparams["checkpoint"]:
+            save_checkpoint(hparams["checkpoint"], epoch, model, optimizer, iter_meter.get())
+        last_cer = avg_cer
     if world > 1:
+        dist.barrier()
         dist.destroy_process_group()
     return last_cer
 

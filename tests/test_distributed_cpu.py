@@ -95,3 +95,55 @@ def test_lr_schedule_matches_reference_formula():
     assert f(100000, 3500, 100000) == 0.0
     assert f(51750, 3500, 100000) == pytest.approx(0.5)
     assert f(200000, 3500, 100000) == 0.0
+
+
+_DYING_RANK = """
+import os, sys, time
+import torch, torch.distributed as dist
+dist.init_process_group("gloo")
+if dist.get_rank() == 1:
+    os._exit(3)                      # dies before the collective: rank 0 would wait in it for the backend's timeout
+t = torch.ones(4)
+dist.all_reduce(t)
+time.sleep(120)
+"""
+
+
+def test_launcher_ends_the_survivors_when_a_rank_dies(tmp_path):
+    """bench.spawn_ranks: one of two gloo ranks exits non-zero before the first collective; the launcher must notice,
+    terminate the rank that is blocked in the all-reduce and return non-zero within seconds (it used to wait for the
+    ranks one after another with no deadline)."""
+    import sys
+    import time
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    import bench
+    script = tmp_path / "rank.py"
+    script.write_text(_DYING_RANK)
+    t0 = time.time()
+    rc = bench.spawn_ranks(2, deadline_s=60, log_dir=str(tmp_path), cmd=[sys.executable, str(script)])
+    dt = time.time() - t0
+    assert rc == 3 and dt < 30, (rc, dt)
+    assert (tmp_path / "bench_rank0.stderr").exists() and (tmp_path / "bench_rank1.stderr").exists()
+
+
+def test_launcher_deadline(tmp_path):
+    """... and a set of ranks that simply never finishes is ended at the deadline with exit code 124."""
+    import sys
+    import time
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    import bench
+    script = tmp_path / "sleep.py"
+    script.write_text("import time\ntime.sleep(120)\n")
+    t0 = time.time()
+    rc = bench.spawn_ranks(2, deadline_s=2, log_dir=str(tmp_path), cmd=[sys.executable, str(script)])
+    assert rc == 124 and time.time() - t0 < 20
+
+
+def test_shard_sampler_covers_every_item_once():
+    from speech_amd.train import ShardSampler
+    for n in (0, 1, 7, 16):
+        for world in (1, 2, 3):
+            for shuffle in (False, True):
+                got = sorted(i for r in range(world) for i in ShardSampler(n, r, world, shuffle))
+                assert got == list(range(n))
+                assert sum(len(ShardSampler(n, r, world, shuffle)) for r in range(world)) == n

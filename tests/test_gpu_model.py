@@ -236,6 +236,77 @@ def test_train_step_reduces_loss_bf16(cuda):
     assert np.isfinite(losses).all() and losses[-1] < 0.7 * losses[0], losses
 
 
+def test_train_step_fp16(cuda):
+    """--dtype fp16 (the reference's AMP type): the whole training step, incl. the fused classifier + CTC node whose
+    gradient leaves the CTC kernels as float16, runs and learns."""
+    from speech_amd.train import FlatAdam, train_step
+    m = _small_model(cuda, dtype=torch.float16, layers=2, dim=64)
+    m.train()
+    opt = FlatAdam(m.parameters(), lr=2e-3, weight_decay=1e-3)
+    g = torch.Generator().manual_seed(3)
+    spec = (torch.rand(4, 1, 80, 161, generator=g) * 3).to(cuda)
+    labels = torch.randint(1, 29, (4, 8), generator=g).to(cuda)
+    ll = torch.tensor([8, 6, 5, 3], dtype=torch.int32, device=cuda)
+    losses = [float(train_step(m, opt, spec, labels, ll, 2.0)) for _ in range(12)]
+    assert np.isfinite(losses).all() and losses[-1] < 0.7 * losses[0], losses
+
+
+def test_ctc_f16_gradient_is_the_rounded_f32_gradient(cuda):
+    from speech_amd import ops
+    g = torch.Generator().manual_seed(5)
+    for T, B, V, L in ((40, 3, 29, 7), (70, 2, 1000, 12)):
+        logits = (torch.randn(B, T, V, generator=g) * 2).to(cuda)
+        labels = torch.randint(1, V, (B, L), generator=g).to(cuda)
+        il = torch.full((B,), T, dtype=torch.int32, device=cuda)
+        ll = torch.randint(1, L + 1, (B,), generator=g).to(torch.int32).to(cuda)
+        _, _, g32 = ops.ctc_fwd_bwd(logits, labels, il, ll, max_label_len=L, grad_scale=64.0)
+        _, _, g16 = ops.ctc_fwd_bwd(logits, labels, il, ll, max_label_len=L, grad_scale=64.0, grad_dtype=torch.float16)
+        assert g16.dtype == torch.float16
+        assert torch.equal(g16, g32.to(torch.float16))
+
+
+def test_ctc_host_label_lengths_beyond_the_bound_raise(cuda):
+    """Host-side lengths are checked against max_label_len before anything is launched (device-side ones are clamped
+    by the kernel, as the header says)."""
+    from speech_amd import ops
+    logits = torch.randn(2, 30, 29, device=cuda)
+    labels = torch.randint(1, 29, (2, 9), device=cuda)
+    il = torch.full((2,), 30, dtype=torch.int32, device=cuda)
+    with pytest.raises(ValueError, match="exceeds max_label_len"):
+        ops.ctc_fwd_bwd(logits, labels, il, torch.tensor([9, 4], dtype=torch.int32), max_label_len=6)
+    ops.ctc_fwd_bwd(logits, labels, il, torch.tensor([6, 4], dtype=torch.int32), max_label_len=6)
+
+
+def test_resume_restores_optimizer_and_schedule(cuda, tmp_path):
+    """save_checkpoint -> resume_from -> the next step is the step the uninterrupted run takes (weights, Adam moments,
+    step count); a bare state_dict restores the weights only."""
+    from speech_amd import train
+    g = torch.Generator().manual_seed(3)
+    spec = (torch.rand(4, 1, 80, 161, generator=g) * 3).to(cuda)
+    labels = torch.randint(1, 29, (4, 8), generator=g).to(cuda)
+    ll = torch.tensor([8, 6, 5, 3], dtype=torch.int32, device=cuda)
+    m = _small_model(cuda, dtype=torch.float32).train()
+    opt = train.FlatAdam(m.parameters(), lr=2e-3, weight_decay=1e-3)
+    for _ in range(3):
+        train.train_step(m, opt, spec, labels, ll, 2.0)
+    path = tmp_path / "ck.pth"
+    train.save_checkpoint(str(path), 2, m, opt, iterations=3)
+    train.train_step(m, opt, spec, labels, ll, 2.0)
+    want = opt.flat.detach().clone()
+    m2 = _small_model(cuda, dtype=torch.float32, seed=5).train()
+    opt2 = train.FlatAdam(m2.parameters(), lr=2e-3, weight_decay=1e-3)
+    epoch, iters = train.resume_from(str(path), m2, opt2)
+    assert (epoch, iters, opt2.t) == (2, 3, 3)
+    train.train_step(m2, opt2, spec, labels, ll, 2.0)
+    # the forward is bit-reproducible; weight gradients add with f32 atomics (last-bit differences through Adam)
+    assert float((opt2.flat - want).abs().max()) <= 2 * 2e-3
+    assert float((opt2.exp_avg - opt.exp_avg).abs().max()) <= 1e-5 * float(opt.exp_avg.abs().max()) + 1e-9
+    m3 = _small_model(cuda, dtype=torch.float32, seed=6)
+    opt3 = train.FlatAdam(m3.parameters(), lr=2e-3)
+    torch.save(m.state_dict(), tmp_path / "bare.pth")
+    assert train.resume_from(str(tmp_path / "bare.pth"), m3, opt3) == (0, 0) and opt3.t == 0
+
+
 def test_scripts_predict_and_eval(cuda, tmp_path):
     import wave
     from speech_amd import data
@@ -534,7 +605,8 @@ def test_train_main_on_disk_corpus(cuda, tmp_path, monkeypatch):
     cer = train.main(hp)
     assert np.isfinite(cer) and cer <= 2.0
     saved = torch.load(ckpt, weights_only=True)
-    assert set(saved) == {"epoch", "model_state_dict", "optimizer_state_dict"} and saved["epoch"] == 1
+    # train.py:171-178's keys (+ the scheduler position a resume needs)
+    assert set(saved) == {"epoch", "model_state_dict", "optimizer_state_dict", "iterations"} and saved["epoch"] == 1
     m = net.SRModel(2, 64, 28, 80, 0.0).to(cuda)
     m.load_checkpoint(saved)
 

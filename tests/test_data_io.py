@@ -163,6 +163,44 @@ def test_build_loaders_mirrors_reference_wiring(corpus, tmp_path):
     assert list(evals[1][1].loader)[0][0][1] == "ibm a"
 
 
+def test_eval_dataset_cli_builds_the_reference_datasets(corpus, tmp_path):
+    """scripts/eval_dataset.py:95-128: `libri` / `tv` / `ibm` / `eval_high_cer` through the dataset classes with the
+    reference's manifest names, shuffle off, whole pre-sorted batches (the IBM directory batched by the loader); argument
+    parsing as `beam_decode dataset_type model_file`.  The raw loaders are walked here; the featuriser needs the GPU."""
+    from speech_amd.scripts import eval_dataset as ev
+    root, libri_entries, tv_entries = corpus
+    mdir = tmp_path / "manifests"
+    (mdir / "datasets" / "librispeech").mkdir(parents=True)
+    (mdir / "datasets" / "librispeech" / "sorted_test_clean_librispeech.pkl").write_bytes(pickle.dumps(libri_entries))
+    for name in ("first", "second", "third", "fourth"):
+        (mdir / "datasets" / name).mkdir(parents=True)
+        (mdir / "datasets" / name / "sorted_eval_cer_0.2.pkl").write_bytes(pickle.dumps(tv_entries if name == "first" else []))
+    (mdir / "eval_paths_0.21cer.pkl").write_bytes(pickle.dumps(tv_entries))
+    ibm = tmp_path / "ibm"
+    ibm.mkdir()
+    for k in range(3):
+        _write_wav(ibm / f"u{k}.wav", np.zeros(3000 + k))
+        (ibm / f"u{k}.txt").write_text(f"ibm {k}")
+    a = ev.parse_args(["False", "libri", "m.pth", "--manifest_root", str(mdir), "--root_map", "/nonexistent=/x"])
+    assert (a.beam_decode, a.dataset_type, a.model_file, a.dtype) == (False, "libri", "m.pth", "fp16")      # model.half()
+    assert a.root_map == (("/nonexistent", "/x"),)
+    ds, bs = ev.build_dataset("libri", 2, str(mdir), a.root_map)
+    assert bs is None and len(ds) == 2              # "test" manifest: nothing cut off its end
+    batches = list(ev.build_loader(ds, bs, 0).loader)
+    assert [len(b) for b in batches] == [2, 2] and batches[0][0][1] == "hello world 0"
+    ds, bs = ev.build_dataset("tv", 2, str(mdir), (("/nonexistent", "/x"),))
+    assert bs is None and len(ds) == 1 and list(ev.build_loader(ds, bs, 0).loader)[0][1][1] == "tv clip 1"
+    ds, bs = ev.build_dataset("eval_high_cer", 1, str(mdir), (("/nonexistent", "/x"),))
+    assert len(ds) == 2
+    ds, bs = ev.build_dataset("ibm", 2, ibm_root=str(ibm))
+    assert bs == 2 and [len(b) for b in ev.build_loader(ds, bs, 0).loader] == [2, 1]
+    with pytest.raises(SystemExit):
+        ev.parse_args(["False", "nope", "m.pth"])
+    with pytest.raises(SystemExit):
+        ev.parse_args(["maybe", "libri", "m.pth"])
+    assert ev.parse_args(["True", "ibm", "m.pth", "--lm", "x.arpa"]).lm == "x.arpa"
+
+
 def test_load_checkpoint_key_tolerance():
     """SRModel.load_checkpoint takes both checkpoint shapes (train.py:171-178 dict, bare state_dict) and tolerates the
     keys whose presence depends on the sru / torch version (scale_x buffers, BatchNorm step counters); anything else

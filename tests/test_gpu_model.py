@@ -307,6 +307,51 @@ def test_resume_restores_optimizer_and_schedule(cuda, tmp_path):
     assert train.resume_from(str(tmp_path / "bare.pth"), m3, opt3) == (0, 0) and opt3.t == 0
 
 
+def test_eval_dataset_cli_on_disk_corpora(cuda, tmp_path):
+    """scripts/eval_dataset.py's command line as the reference wires it (:70-129): `libri` through SortedLibriSpeech on a
+    LibriSpeech-layout stand-in, `ibm` through IBMDataset batched by the loader; fp16 activations by default
+    (model.half()); greedy and beam decode."""
+    import pickle
+    import wave
+    from speech_amd.scripts import eval_dataset as ev
+    rs = np.random.RandomState(4)
+
+    def wav(path, n):
+        with wave.open(str(path), "wb") as f:
+            f.setnchannels(1); f.setsampwidth(2); f.setframerate(16000)
+            f.writeframes((rs.randn(n) * 2500).clip(-32768, 32767).astype("<i2").tobytes())
+    libri = tmp_path / "LibriSpeech" / "test-clean" / "7" / "11"
+    libri.mkdir(parents=True)
+    entries, lines = [], []
+    for k, n in enumerate([5000, 5600, 6100, 6900]):
+        fid = f"7-11-{k:04d}"
+        wav(libri / (fid + ".wav"), n)
+        lines.append(f"{fid} SOME WORDS HERE")
+        entries.append((str(libri / (fid + ".wav")), n))
+    (libri / "7-11.trans.txt").write_text("\n".join(lines) + "\n")
+    mdir = tmp_path / "m"
+    (mdir / "datasets" / "librispeech").mkdir(parents=True)
+    (mdir / "datasets" / "librispeech" / "sorted_test_clean_librispeech.pkl").write_bytes(pickle.dumps(entries))
+    ibm = tmp_path / "ibm"
+    ibm.mkdir()
+    for k in range(3):
+        wav(ibm / f"i{k}.wav", 6000 + 300 * k)
+        (ibm / f"i{k}.txt").write_text("ibm line")
+    m = _small_model(cuda, layers=2, dim=64)
+    ckpt = tmp_path / "m.pth"
+    torch.save(m.state_dict(), ckpt)                         # a bare state_dict, as eval_dataset.py:119 loads it
+    common = ["--n_rnn_layers", "2", "--rnn_dim", "64", "--batch_size", "2", "--num_workers", "0"]
+    logs = []
+    cer, wer = ev.main(["False", "libri", str(ckpt), "--manifest_root", str(mdir), "--root_map", "/nowhere=/x"] + common,
+                       log=logs.append)
+    assert np.isfinite(cer) and np.isfinite(wer) and any("Average CER" in str(l) for l in logs)
+    cer32, _ = ev.main(["False", "libri", str(ckpt), "--manifest_root", str(mdir), "--root_map", "/nowhere=/x",
+                        "--dtype", "fp32"] + common, log=lambda *a: None)
+    assert abs(cer - cer32) <= 0.25                          # an untrained model: the two precisions decode alike
+    cer_b, _ = ev.main(["True", "ibm", str(ckpt), "--ibm_root", str(ibm)] + common, log=lambda *a: None)
+    assert np.isfinite(cer_b)
+
+
 def test_scripts_predict_and_eval(cuda, tmp_path):
     import wave
     from speech_amd import data

@@ -34,8 +34,15 @@ HBM_PEAK_GBS = 8000.0      # MI355X_MICROARCH.md: HBM3E 8 TB/s
 PMC_TRAFFIC_BYTES = {
     ("sru_bwd_kernel", "bf16", 32, 15.0): 2 * 144257.0 * 1024 + 193024.0 * 1024,
     ("sru_fwd_kernel", "bf16", 32, 15.0): 2 * 96184.9 * 1024 + 96128.0 * 1024,
-    # L2-miss side of the forward GEMM (tools/pmc_gemm.py fwd): B panels stay L2-resident per XCD, A is
-    # streamed once per owning XCD; algorithmic 55.5 MB read + 147.7 MB written
+    # round 3 (profiles/r03_gemm_pmc.md, tools/pmc_gemm.py, per launch): bytes that left the L2s -- the Infinity Cache
+    # serves part of them, the counters cannot tell.  Forward: A (49 MB) is re-streamed by every XCD once per group
+    # of four tile columns, B (6 MB) once per XCD and group; algorithmic 55.5 MB read + 147.7 MB written.
+    ("gemm_nt(forward projection U = LN(x) W)", "bf16", 32, 15.0): 2 * 127609.6 * 1024 + 144248.8 * 1024,
+    ("gemm_nt(data gradient gX = gU W^T)", "bf16", 32, 15.0): 2 * 123362.9 * 1024 + 48064.0 * 1024,
+    ("gemm_tn(weight gradient dW = LN(x)^T gU, split-K)", "bf16", 32, 15.0): 2 * 137164.3 * 1024 + 61440.5 * 1024,
+    # round 2 (profiles/r02_pmc_traffic.md; kernels unchanged since)
+    ("melspec_kernel", "bf16", 32, 15.0): 2 * 16019.0 * 1024 + 18300.0 * 1024,
+    ("ctc_fwd_bwd(3 kernels)", "bf16", 32, 15.0): (2 * 47032.0 + 2 * 52370.0 + 2 * 21862.0 + 4882.0 + 142004.0 + 29987.0) * 1024,
 }
 MFMA_BF16_PEAK_TF = 2500.0  # dense bf16
 

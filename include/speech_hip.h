@@ -294,6 +294,23 @@ int sp_block_out(const void* y2, const float* coef, const void* x, int B, int F,
 int sp_block_bwd_in(const void* gz, const void* z, int64_t zsb, int64_t zsf, int64_t zst,
                     const void* y2, int B, int F, int T, void* gpre, float* sums, void* stream);
 
+/* The conv stack in fp32, for EVALUATION outside autocast (train.py:105-135 and :162-168 run net.py:56-59 and
+ * :6-42 in fp32; scripts/predict.py:40-47 on the CPU): one f32 convolution with the inference BatchNorm folded in.
+ *   out(b, f, t, co) = act( scale[co] * sum_{kh, kw, ci} x(b, f*stride + kh - KH/2, t*stride + kw - KW/2, ci) * w[kh][kw][ci][co]
+ *                           + shift[co] + res(b, f, t, co) )
+ * x: f32, element (b, f, t, ci) at x[b*xsb + f*xsf + t*xst + ci], Cin = 1 (the spectrogram, net.py:56) or 32;
+ * w: f32 [KH][KW][Cin][32] (the state_dict's [32][Cin][KH][KW] permuted by the caller); zero padding of KH/2, KW/2
+ * (odd kernels); stride 1 or 2; scale / shift: f32 [32] -- (1, bias) for a plain convolution, (gamma / sqrt(var +
+ * eps), (bias - mean) * that + beta) for conv + BatchNorm on running statistics; res: NULL or f32 with its own strides
+ * (the residual of net.py:38-40); relu != 0: act = max(., 0).  out / res: element (b, f, t, co) at [b*osb + f*osf +
+ * t*ost + co] (so the last block can write [T'][B][F*32] directly, net.py:81-83); Fout = (Fin - 1) / stride + 1.
+ * f32 operands and f32 accumulation in one fixed order per output (vector ALUs, no MFMA): results do not depend on
+ * the launch.  Pointers 16-byte aligned, strides multiples of 4 elements (x: only when Cin = 32). */
+int sp_conv2d_f32(const float* x, int64_t xsb, int64_t xsf, int64_t xst, int Cin, const float* w, const float* scale,
+                  const float* shift, const float* res, int64_t rsb, int64_t rsf, int64_t rst, int relu, int B,
+                  int Fin, int Tin, int KH, int KW, int stride, float* out, int64_t osb, int64_t osf, int64_t ost,
+                  void* stream);
+
 /* Projection-weight layout conversion around the SRU projection GEMM (net.py:61-72; the sru
  * package stores weight[n_in][dir][d][k]).  sp_sru_pack_w: f32 state_dict weight -> Wk[n_in][k][dir][d]
  * in dtype (SP_F32 / SP_BF16), rows re-ordered from c*F + f to f*C + c (C = 1: unchanged; F = n_in/C)

@@ -57,6 +57,8 @@ SIGNATURES = {
     "sp_bn_finalize_bwd": (_i, [_vp, _vp, _vp, _i64, _vp, _vp, _vp, _vp]),
     "sp_block_out": (_i, [_vp, _vp, _vp, _i, _i, _i, _vp, _i64, _i64, _i64, _vp]),
     "sp_block_bwd_in": (_i, [_vp, _vp, _i64, _i64, _i64, _vp, _i, _i, _i, _vp, _vp, _vp]),
+    "sp_conv2d_f32": (_i, [_vp, _i64, _i64, _i64, _i, _vp, _vp, _vp, _vp, _i64, _i64, _i64, _i, _i, _i, _i, _i, _i, _i,
+                           _vp, _i64, _i64, _i64, _vp]),
     "sp_sru_pack_w": (_i, [_vp, _i, _i, _i, _i, _i, _vp, _vp]),
     "sp_sru_pack_wt": (_i, [_vp, _i, _i, _i, _i, _i, _vp, _i64, _vp, _vp]),
     "sp_sru_pack_wt_batched": (_i, [_vp, _i, _i, _i, _i, _i, _i, _vp, _i64, _vp, _vp]),

@@ -193,6 +193,52 @@ class _ConvStackFn(torch.autograd.Function):
         return (None, None, None, None, gsw.view(32, 1, 3, 3), gsb, *grads, *([None] * (4 * nblk)))
 
 
+def _conv_f32(x, xs, cin, w, scale, shift, res, rs, relu, B, Fin, Tin, stride, out, os_):
+    """One sp_conv2d_f32 launch; xs / rs / os_ = (batch, frequency, time) strides in elements."""
+    KH, KW = int(w.shape[0]), int(w.shape[1])
+    rs = rs or (0, 0, 0)
+    check(lib().sp_conv2d_f32(ptr(x), xs[0], xs[1], xs[2], cin, ptr(w), ptr(scale), ptr(shift), ptr(res), rs[0], rs[1], rs[2],
+                              int(relu), B, Fin, Tin, KH, KW, stride, ptr(out), os_[0], os_[1], os_[2], stream_ptr()),
+          "sp_conv2d_f32")
+    return out
+
+
+@torch.no_grad()
+def conv_stack_eval_f32(spec, cnn, blocks):
+    """The conv stack of net.py:56-59 / :6-42 in fp32 with BatchNorm on its running statistics -- what the reference's
+    evaluation computes outside autocast (train.py:105-135, :162-168).  Same output layout as conv_stack:
+    [T', B, F*32], feature index f*32 + c, f32.  The convolution weights are permuted to [KH][KW][Cin][32] and the
+    BatchNorm folded into (scale, shift) here, on parameter-sized tensors; everything activation-sized runs in
+    sp_conv2d_f32."""
+    spec = spec.detach().float().contiguous()
+    B, _, Fin, Tin = spec.shape
+    F, T = (Fin - 1) // 2 + 1, (Tin - 1) // 2 + 1
+    dev = spec.device
+    with torch.cuda.device(dev):
+        ones = torch.ones(C, dtype=torch.float32, device=dev)
+        chl = (F * T * C, T * C, C)                                   # [B][F][T][32]
+        x = torch.empty((B, F, T, C), dtype=torch.float32, device=dev)
+        _conv_f32(spec, (Fin * Tin, Tin, 1), 1, _f32(cnn.weight).permute(2, 3, 1, 0).contiguous(), ones, _f32(cnn.bias),
+                  None, None, False, B, Fin, Tin, 2, x, chl)
+
+        def fold(conv, bn):
+            scale = _f32(bn.weight) / torch.sqrt(_f32(bn.running_var) + bn.eps)
+            shift = (_f32(conv.bias) - _f32(bn.running_mean)) * scale + _f32(bn.bias)
+            return _f32(conv.weight).permute(2, 3, 1, 0).contiguous(), scale.contiguous(), shift.contiguous()
+        for i, blk in enumerate(blocks):
+            w1, sc1, sh1 = fold(blk.conv1, blk.bn1)
+            w2, sc2, sh2 = fold(blk.conv2, blk.bn2)
+            y1 = torch.empty((B, F, T, C), dtype=torch.float32, device=dev)
+            _conv_f32(x, chl, C, w1, sc1, sh1, None, None, True, B, F, T, 1, y1, chl)
+            if i == len(blocks) - 1:                                  # [T'][B][F*32]
+                z, zs = torch.empty((T, B, F * C), dtype=torch.float32, device=dev), (F * C, C, B * F * C)
+            else:
+                z, zs = torch.empty((B, F, T, C), dtype=torch.float32, device=dev), chl
+            _conv_f32(y1, chl, C, w2, sc2, sh2, x, chl, True, B, F, T, 1, z, zs)
+            x = z
+    return x
+
+
 def conv_stack(spec, cnn, blocks, training):
     """cnn: nn.Conv2d(1,32,3,stride 2); blocks: iterable of ResidualBlock modules."""
     params, bufs = [], []

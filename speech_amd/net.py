@@ -7,7 +7,9 @@ state_dict keys: cnn.{weight,bias}; resnet_layers.{0,1,2}.
 (+ scale_x buffer; + weight_proj when projection_size > 0); classifier.0.{weight,bias}; classifier.1.weight.
 
 The conv/BatchNorm stack (speech_amd.convstack) and the SRU recurrence (ops.sru_recurrence) run
-in the HIP kernels.  The conv stack always keeps bf16 activations; ``compute_dtype`` selects the
+in the HIP kernels.  The training-path conv kernels keep bf16 activations; an fp32 evaluation (eval mode, no
+grad, compute_dtype float32 -- what train.eval_dataset and scripts/predict run) takes the f32 convolution
+kernel instead, so that it is fp32 end to end like the reference's.  ``compute_dtype`` selects the
 activation type of the SRU stack and classifier: float32, bfloat16 (the training type here) or
 float16 (the reference trains under fp16 autocast with an fp16 recurrence, net.py:71, and evaluates
 with model.half(), scripts/eval_dataset.py).  ResidualBlock.forward below is the plain
@@ -193,8 +195,12 @@ class SRModel(nn.Module):
     def encode(self, x):
         """[B, 1, F, T] f32 spectrogram -> layer-normed encoder output, time-major [T', B, 2*rnn_dim]."""
         cd = self.compute_dtype
-        # conv stack on the channel-last bf16 kernels -> [T', B, (F/2)*32], feature = f*32 + c
-        x = convstack.conv_stack(x, self.cnn, list(self.resnet_layers), self.training)
+        if cd == torch.float32 and not self.training and not torch.is_grad_enabled():
+            # fp32 evaluation (train.py:162-168, outside autocast): the conv stack in f32 as well
+            x = convstack.conv_stack_eval_f32(x, self.cnn, list(self.resnet_layers))
+        else:
+            # conv stack on the channel-last bf16 kernels -> [T', B, (F/2)*32], feature = f*32 + c
+            x = convstack.conv_stack(x, self.cnn, list(self.resnet_layers), self.training)
         x, _ = self.sru_layers(x.to(cd))
         ln = self.classifier[0]
         return ops.layer_norm(x, ln.weight, ln.bias, ln.eps)

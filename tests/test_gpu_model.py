@@ -45,10 +45,12 @@ def test_state_dict_layout_matches_reference_names(cuda):
 
 @pytest.mark.parametrize("train", [False, True])
 def test_model_forward_matches_cpu_oracle(cuda, train):
-    """SRModel on the HIP kernels (f32 SRU stack, bf16 conv stack) vs oracle.net on the CPU with the
-    same state_dict.  Against the plain f32 oracle: 2.5 % of the logit range (measured 0.5 % eval / 1.2 % train: the
-    conv stack keeps bf16 activations); against the oracle that rounds to bf16 where the conv stack does: 1 %
-    (measured 0.15 % / 0.56 %: accumulation order and the batch statistics of unrounded sums)."""
+    """SRModel on the HIP kernels vs oracle.net on the CPU with the same state_dict.
+    eval (the reference's fp32 evaluation, train.py:162-168): fp32 end to end -- f32 conv kernel, f32 SRU stack --
+    within 2e-3 of the logit range of the plain f32 oracle.
+    train (batch-statistics BatchNorm, bf16 conv stack, f32 SRU stack): 2.5 % of the logit range against the plain f32
+    oracle (measured 1.2 %), 1 % against the oracle that rounds to bf16 where the conv stack does (measured 0.56 %:
+    accumulation order and the batch statistics of unrounded sums)."""
     m = _small_model(cuda)
     m.train(train)
     g = torch.Generator().manual_seed(1)
@@ -59,11 +61,50 @@ def test_model_forward_matches_cpu_oracle(cuda, train):
         ref = onet.forward(sd, spec, 2, 64, training=train)
         ref_q = onet.forward(sd, spec, 2, 64, training=train, bf16_conv=True)
     assert out.shape == ref.shape == (2, 61, 29)
-    assert float((out - ref).abs().max()) <= 2.5e-2 * float(ref.abs().max())
-    # against the oracle that rounds where the conv stack rounds, what is left is accumulation order
-    print("encoder forward: max error vs f32 oracle %.4f, vs bf16-rounding oracle %.4f of the logit range" %
-          (float((out - ref).abs().max()) / float(ref.abs().max()), float((out - ref_q).abs().max()) / float(ref_q.abs().max())))
-    assert float((out - ref_q).abs().max()) <= 1e-2 * float(ref_q.abs().max())
+    err = float((out - ref).abs().max()) / float(ref.abs().max())
+    err_q = float((out - ref_q).abs().max()) / float(ref_q.abs().max())
+    print("encoder forward (train=%s): max error vs f32 oracle %.5f, vs bf16-rounding oracle %.5f of the logit range" % (train, err, err_q))
+    if train:
+        assert err <= 2.5e-2
+        assert err_q <= 1e-2      # against the oracle that rounds where the conv stack rounds: accumulation order
+    else:
+        assert err <= 2e-3
+
+
+def test_conv2d_f32_matches_torch(cuda):
+    """sp_conv2d_f32 (the fp32 evaluation's conv kernel) against torch's CPU convolution in f32: the stem (1 -> 32,
+    3 x 3, stride 2), a block convolution (32 -> 32, 3 x 5) with folded BatchNorm + ReLU, and one with the residual, in
+    both output layouts; ragged sizes."""
+    from speech_amd import convstack
+    g = torch.Generator().manual_seed(4)
+    for B, Fin, Tin in ((2, 80, 121), (1, 7, 9), (3, 16, 300)):
+        spec = torch.randn(B, 1, Fin, Tin, generator=g)
+        w = torch.randn(32, 1, 3, 3, generator=g) * 0.3
+        bias = torch.randn(32, generator=g)
+        ref = torch.nn.functional.conv2d(spec, w, bias, stride=2, padding=1)                  # [B, 32, F, T]
+        F, T = ref.shape[2], ref.shape[3]
+        out = torch.empty((B, F, T, 32), device=cuda)
+        convstack._conv_f32(spec.to(cuda), (Fin * Tin, Tin, 1), 1, w.permute(2, 3, 1, 0).contiguous().to(cuda),
+                            torch.ones(32, device=cuda), bias.to(cuda), None, None, False, B, Fin, Tin, 2, out,
+                            (F * T * 32, T * 32, 32))
+        assert float((out.cpu().permute(0, 3, 1, 2) - ref).abs().max()) <= 1e-5 * float(ref.abs().max())
+        x = torch.randn(B, 32, F, T, generator=g)
+        w2 = torch.randn(32, 32, 3, 5, generator=g) * 0.05
+        sc, sh = torch.rand(32, generator=g) + 0.5, torch.randn(32, generator=g)
+        res = torch.randn(B, 32, F, T, generator=g)
+        conv = torch.nn.functional.conv2d(x, w2, None, padding=(1, 2))
+        ref1 = torch.relu(conv * sc.view(1, -1, 1, 1) + sh.view(1, -1, 1, 1))
+        ref2 = torch.relu(conv * sc.view(1, -1, 1, 1) + sh.view(1, -1, 1, 1) + res)
+        xl, rl = x.permute(0, 2, 3, 1).contiguous().to(cuda), res.permute(0, 2, 3, 1).contiguous().to(cuda)
+        chl = (F * T * 32, T * 32, 32)
+        wl = w2.permute(2, 3, 1, 0).contiguous().to(cuda)
+        o1 = convstack._conv_f32(xl, chl, 32, wl, sc.to(cuda), sh.to(cuda), None, None, True, B, F, T, 1,
+                                 torch.empty((B, F, T, 32), device=cuda), chl)
+        assert float((o1.cpu().permute(0, 3, 1, 2) - ref1).abs().max()) <= 2e-5 * float(ref1.abs().max())
+        o2 = convstack._conv_f32(xl, chl, 32, wl, sc.to(cuda), sh.to(cuda), rl, chl, True, B, F, T, 1,
+                                 torch.empty((T, B, F * 32), device=cuda), (F * 32, 32, B * F * 32))      # [T][B][F*32]
+        got = o2.cpu().view(T, B, F, 32).permute(1, 3, 2, 0)
+        assert float((got - ref2).abs().max()) <= 2e-5 * float(ref2.abs().max())
 
 
 LOSS_TOL, GRAD_TOL = 5e-3, 2e-2   # measured: loss 4e-4, gradients behind the conv stack 3e-3 .. 5e-3
@@ -102,8 +143,9 @@ def test_model_gradients_match_cpu_oracle(cuda):
         a, b, c = named[k].grad.cpu(), ref_grads[k], q_grads[k]
         print("%-45s f32 oracle %.4f  bf16-rounding oracle %.4f" % (k, float((a - b).abs().max()) / float(b.abs().max()),
                                                                      float((a - c).abs().max()) / float(c.abs().max())))
-        assert float((a - b).abs().max()) <= 2e-1 * float(b.abs().max()) + 1e-7, k
-        assert float((a - c).abs().max()) <= 1e-1 * float(c.abs().max()) + 1e-7, k
+        assert float((a - b).abs().max()) <= 1.5e-1 * float(b.abs().max()) + 1e-7, k     # measured <= 12.1 %
+        assert float((a - c).abs().max()) <= 5e-2 * float(c.abs().max()) + 1e-7, k       # measured <= 4.4 %; the kernels
+        # on this path add in fixed orders (no float atomics feed these gradients), so the figures do not move from run to run
         cos = float((a.flatten() * c.flatten()).sum() / (a.norm() * c.norm()))
         print("    cosine with the rounding oracle %.5f" % cos)
         assert cos >= 0.995, k

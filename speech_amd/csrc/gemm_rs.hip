@@ -489,15 +489,14 @@ __global__ __launch_bounds__(768, 3) void gemm_tn_rs_kernel(TnArgs g) {
     const int wi = wave >> 2, wj = wave & 3;
     const int li = lane & 15, q = lane >> 4, qq = li >> 2, p = li & 3;
     // transposed-read address of this lane inside a [64 k][256] part: row 8 q + qq (+ 32 kk, + 4 for the second
-    // half of the fragment), 32-byte group (block) ^ sk, byte (p >> 1) * 16 + (p & 1) * 8 inside the group
+    // half of the fragment), 32-byte group (block) ^ sk, byte (p >> 1) * 16 + (p & 1) * 8 inside the group.
+    // block = 8 wi + a (X) / 4 wj + b (G) with sk < 8 and a < 8, b < 4: fragment a's address is fragment 0's ^ (a << 5)
+    // (one v_xor per fragment instead of twelve address registers: the registers go to the fragment pipeline below)
     const int sk = qq | ((q & 1) << 2);
     const int rowoff = (8 * q + qq) * 512 + (p >> 1) * 16 + (p & 1) * 8;
     const uint32_t lds0 = (uint32_t)(uintptr_t)(rs_lptr_t)smem;
-    uint32_t ax[MB], ag[NB];
-#pragma unroll
-    for (int a = 0; a < MB; ++a) ax[a] = lds0 + rowoff + ((((wi * 8 + a) & 15) ^ sk) << 5);
-#pragma unroll
-    for (int b = 0; b < NB; ++b) ag[b] = lds0 + GOFF + rowoff + ((((wj * 4 + b) & 15) ^ sk) << 5);
+    const uint32_t xb0 = lds0 + rowoff + (((wi * 8) ^ sk) << 5);
+    const uint32_t gb0 = lds0 + GOFF + rowoff + ((((wj * 4) & 15) ^ sk) << 5);
 
     rs_f32x4 acc[MB][NB];
 #pragma unroll
@@ -518,30 +517,52 @@ __global__ __launch_bounds__(768, 3) void gemm_tn_rs_kernel(TnArgs g) {
     for (int step = 0; step < total; ++step) {
         __builtin_amdgcn_s_barrier();
         asm volatile("" ::: "memory");
+        // Fragment pipeline: the X fragment of group n + 1 (a group = one X fragment against the wave's four G
+        // fragments) is requested BEFORE the four MFMAs of group n, the G set of the step's second half fragment by
+        // fragment behind the last MFMAs that read the first half's; the sched_group_barrier sequence pins that order
+        // (left alone, the scheduler sinks every read to just in front of its use: two reads, a full wait and four
+        // MFMAs per group, the LDS round trip exposed sixteen times a step).
+        const uint32_t xb = xb0 + sx * PART, gb = gb0 + sg * PART;
+        rs_bf16x8 Pf[NB], Q, Qn;
 #pragma unroll
-        for (int kk = 0; kk < 2; ++kk) {
-            const uint32_t kx = sx * PART + kk * 32 * 512, kg = sg * PART + kk * 32 * 512;
-            rs_bf16x8 Pf[NB];
+        for (int b = 0; b < NB; ++b) Pf[b] = frag(gb ^ (uint32_t)(b << 5));
+        Q = frag(xb);
+        __builtin_amdgcn_sched_group_barrier(0x100, 10, 0);
 #pragma unroll
-            for (int b = 0; b < NB; ++b) Pf[b] = frag(ag[b] + kg);
-#pragma unroll
-            for (int a = 0; a < MB; ++a) {
-                const rs_bf16x8 Q = frag(ax[a] + kx);
-#pragma unroll
-                for (int b = 0; b < NB; ++b) acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(Pf[b], Q, acc[a][b], 0, 0, 0);
+        for (int n = 0; n < 16; ++n) {
+            const int kk = n >> 3, a = n & 7;
+            if (n < 15) {
+                Qn = frag((xb ^ (uint32_t)(((n + 1) & 7) << 5)) + ((n + 1) >> 3) * 32 * 512);
+                __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
             }
+#pragma unroll
+            for (int b = 0; b < NB; ++b) {
+                acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(Pf[b], Q, acc[a][b], 0, 0, 0);
+                if (n == 7) {     // the second half's G fragment b, behind the last MFMA that reads the first half's
+                    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                    Pf[b] = frag((gb ^ (uint32_t)(b << 5)) + 32 * 512);
+                    __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
+                }
+            }
+            if (n != 7) __builtin_amdgcn_sched_group_barrier(0x008, 4, 0);
+            (void)kk;
+            Q = Qn;
         }
         asm volatile("" ::: "memory");
         sx ^= 1;
         sg = sg + 1 == NSG ? 0 : sg + 1;
         if (++ck == csteps) {
-            // D[row = j][col = i]: lane = (i = li, q), register e -> j = 4 q + e
+            // D[row = j][col = i]: lane = (i = li, q), register e -> j = 4 q + e (li, q re-derived from an opaque copy of
+            // the lane number: held across the K loop they cost registers the loop has none of to spare)
+            int le = lane;
+            asm volatile("" : "+v"(le));
+            const int eli = le & 15, eq = le >> 4;
             const int z = citem / ntiles, t = citem % ntiles;
             const int i0 = (t % g.nti) * BI + wi * 128, j0 = (t / g.nti) * BJ + wj * 64;
             float* Pz = g.P + (int64_t)z * g.slab;
 #pragma unroll
             for (int a = 0; a < MB; ++a) {
-                float* crow = Pz + (int64_t)(i0 + a * 16 + li) * g.ldp + j0 + 4 * q;
+                float* crow = Pz + (int64_t)(i0 + a * 16 + eli) * g.ldp + j0 + 4 * eq;
 #pragma unroll
                 for (int b = 0; b < NB; ++b) {
                     *reinterpret_cast<rs_f32x4*>(crow + b * 16) = acc[a][b];

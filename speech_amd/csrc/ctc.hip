@@ -163,6 +163,71 @@ __global__ __launch_bounds__(256) void ctc_rows_kernel(
     }
 }
 
+// K1, small vocabularies (V <= HALF, HALF = 32 or 64: the reference's 29 characters, text.py:1-12): a row is at most
+// 256 bytes, so one wave per row spends a memory round trip and two wave reductions on 29 numbers (35 us for 64 x 1501
+// rows).  Here a wave takes 64 / HALF rows side by side (lane = class within its row, reductions within HALF lanes) and
+// kIt of such groups at once: every load of the 4 (8) rows is in flight before the first reduction starts.
+template <int HALF>
+__global__ __launch_bounds__(256) void ctc_rows_small_kernel(
+    const float* __restrict__ logits, int64_t st, int64_t sb, const int64_t* __restrict__ labels,
+    int label_stride, const int32_t* __restrict__ in_len, const int32_t* __restrict__ lab_len,
+    int T, int B, int V, int blank, int Lmax, int RW, int modeB, float* __restrict__ lse2,
+    float* __restrict__ rows) {
+    constexpr int PER = 64 / HALF, kIt = 4, NR = PER * kIt;
+    const int lane = threadIdx.x & 63, sub = lane / HALF, c = lane % HALF;
+    const int wpb = blockDim.x >> 6;
+    const int64_t nrows = (int64_t)T * B;
+    auto red_max = [](float v) {
+#pragma unroll
+        for (int o = HALF / 2; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o));
+        return v;
+    };
+    auto red_sum = [](float v) {
+#pragma unroll
+        for (int o = HALF / 2; o > 0; o >>= 1) v += __shfl_xor(v, o);
+        return v;
+    };
+    for (int64_t r0 = ((int64_t)blockIdx.x * wpb + (threadIdx.x >> 6)) * NR; r0 < nrows; r0 += (int64_t)gridDim.x * wpb * NR) {
+        float z[kIt];
+        int bb[kIt], tt[kIt];
+        bool live[kIt];
+#pragma unroll
+        for (int i = 0; i < kIt; ++i) {
+            const int64_t r = r0 + i * PER + sub;      // (b, t) batch-major, as the other row kernels
+            const int64_t rc = min(r, nrows - 1);
+            bb[i] = (int)(rc / T);
+            tt[i] = (int)(rc % T);
+            live[i] = r < nrows && tt[i] < min(max(in_len[bb[i]], 0), T);
+            z[i] = (live[i] && c < V) ? logits[tt[i] * st + bb[i] * sb + c] : -INFINITY;
+        }
+#pragma unroll
+        for (int i = 0; i < kIt; ++i) {
+            const float m = red_max(z[i]);
+            const float e = (c < V) ? exp2f((z[i] - m) * kLog2e) : 0.f;
+            const float sum = red_sum(live[i] ? e : 0.f);
+            const float l2 = m * kLog2e + log2f(sum);
+            if (!live[i]) continue;       // uniform within the HALF lanes of a row
+            const int64_t row = (int64_t)bb[i] * T + tt[i];
+            if (c == 0) lse2[row] = l2;
+            float* out = rows + row * RW;
+            if (modeB) {
+                if (c < V) out[c] = z[i] * kLog2e - l2;
+            } else {
+                // by label position: lane c fetches class idx's score from the lane that holds it
+                const int L = min(max(lab_len[bb[i]], 0), Lmax);
+                for (int p0 = 0; p0 <= L; p0 += HALF) {
+                    const int pos = p0 + c;
+                    int idx = blank;
+                    if (pos > 0 && pos <= L) idx = (int)labels[(int64_t)bb[i] * label_stride + pos - 1];
+                    idx = min(max(idx, 0), V - 1);
+                    const float zi = __shfl(z[i], sub * HALF + idx);
+                    if (pos <= L) out[pos] = zi * kLog2e - l2;
+                }
+            }
+        }
+    }
+}
+
 // K1, vector path (V % 4 == 0, 16-byte aligned rows, V <= 1024 * NV / 4): the row is read ONCE with
 // float4 loads and stays in registers for the max, the sum and (mode B) the normalised row.
 template <int NV>
@@ -1217,7 +1282,10 @@ extern "C" int sp_ctc_fwd_bwd(const float* logits, int64_t stride_t, int64_t str
                          ((uintptr_t)logits & 15) == 0 && V <= 2048;
 #define SP_ROWS_ARGS logits, stride_t, stride_b, labels, label_stride, input_lengths, label_lengths, T, B, V, \
                      blank, max_label_len, d.RW, d.modeB, ws + d.off_lse, ws + d.off_rows
-        if (vec && V <= 256) hipLaunchKernelGGL((ctc_rows_vec_kernel<1>), dim3(row_blocks), dim3(256), 0, s, SP_ROWS_ARGS);
+        const int small_blocks = (int)std::min<int64_t>(((int64_t)T * B + 31) / 32, 16384);
+        if (V <= 32) hipLaunchKernelGGL((ctc_rows_small_kernel<32>), dim3(small_blocks), dim3(256), 0, s, SP_ROWS_ARGS);
+        else if (V <= 64) hipLaunchKernelGGL((ctc_rows_small_kernel<64>), dim3(small_blocks), dim3(256), 0, s, SP_ROWS_ARGS);
+        else if (vec && V <= 256) hipLaunchKernelGGL((ctc_rows_vec_kernel<1>), dim3(row_blocks), dim3(256), 0, s, SP_ROWS_ARGS);
         else if (vec && V <= 512) hipLaunchKernelGGL((ctc_rows_vec_kernel<2>), dim3(row_blocks), dim3(256), 0, s, SP_ROWS_ARGS);
         else if (vec && V <= 1024) hipLaunchKernelGGL((ctc_rows_vec_kernel<4>), dim3(row_blocks), dim3(256), 0, s, SP_ROWS_ARGS);
         else if (vec) hipLaunchKernelGGL((ctc_rows_vec_kernel<8>), dim3(row_blocks), dim3(256), 0, s, SP_ROWS_ARGS);

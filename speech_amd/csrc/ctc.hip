@@ -76,25 +76,43 @@ constexpr int kCUs = 256;        // MI355X
 constexpr int kAuxDummy = 512;   // doubles of the single-wave kernel's dummy spill row (64 lanes x up to 8 states)
 constexpr int kLat1Threads = 512;      // workgroup of ctc_lattice1_kernel: with kLat1DynLds one workgroup owns a CU
 constexpr int kLat1DynLds = 20 * 1024;  // unused dynamic LDS on top of the 64 KB of emissions: a second workgroup does not fit
-constexpr int kSingleWaveMaxS = 512;   // lattices up to this many states run on ctc_lattice1_kernel
+constexpr int kSingleWaveMaxS = 1024;  // lattices up to this many states run on ctc_lattice1_kernel
+constexpr int kSplitMaxS = 512;        // ... and up to this many have a sparse-half kernel (dense half beside the lattice)
 
-// Column of lattice state p in a spilled row.  The kernel with eight states per lane stores a lane's four state pairs
-// 1 KB apart ([pair][lane][2]: each of its four stores per frame is one contiguous KB; with a lane's 64 bytes side by
-// side in the row, every store touched all of the row's 64-byte sectors a quarter each and the recursion paid 35 us
-// of 141 for it; at four states per lane the same change measured nothing); 64 consecutive states are then whole
-// 128-byte lines, so the consumers' reads stay coalesced.
-__device__ __forceinline__ int spill_col(int p, int perm) {   // perm = log2(states per lane) of the producer, or 0
-    return perm ? ((p & ((1 << perm) - 2)) << 6) + ((p >> perm) << 1) + (p & 1) : p;
+// Lattices of eight and sixteen states per lane (256 < S <= 1024) are spilled PACKED: exponent and the upper 21 bits
+// of the mantissa of each f64 state (states are never negative: the sign bit's place goes to the mantissa), four bytes
+// a state, truncated by the producer and read back as the middle of the truncation interval.  At these sizes the
+// spill and its read-back are what the lattice and the gradient kernel wait for (30 s of characters, 64 utterances:
+// 1.4 GB each way in f64); the posterior keeps 2^-21 relative precision, two hundred times inside the 1e-4 bound,
+// and the likelihood itself is taken from the registers in full f64.
+// Column of lattice state p in a packed row: a lane's states in quads, the quads 1 KB apart ([quad][lane][4]: each
+// store of the recursion wave is one contiguous KB; with a lane's bytes side by side in the row every store touched
+// all of the row's sectors a fraction each and the recursion paid 35 us of 141 for it); 64 consecutive states are
+// then whole 64-byte pieces of NS / 4 planes, so the consumers' reads stay coalesced.
+__device__ __forceinline__ int spill_col(int p, int perm) {   // perm = log2(states per lane) of the packed producer, or 0
+    return perm ? ((p & ((1 << perm) - 4)) << 6) + ((p >> perm) << 2) + (p & 3) : p;
+}
+__device__ __forceinline__ uint32_t lat_pack(double x) {   // one instruction on the recursion wave (v_alignbit_b32)
+    return __builtin_amdgcn_alignbit((uint32_t)__double2hiint(x), (uint32_t)__double2loint(x), 31);
+}
+__device__ __forceinline__ double lat_unpack(uint32_t w) {   // the middle of the interval the truncation left; 0 stays 0
+    return __hiloint2double((int)(w >> 1), w ? (int)((w << 31) | 0x40000000u) : 0);
+}
+// state (row, col) of a lattice block: packed words (perm != 0) or doubles
+__device__ __forceinline__ double lat_load(const void* base, int64_t row, int SP, int col, int perm) {
+    if (perm) return lat_unpack(reinterpret_cast<const uint32_t*>(base)[row * SP + col]);
+    return reinterpret_cast<const double*>(base)[row * SP + col];
 }
 
 struct CtcDims {
     int T, B, V, Lmax;
     int RW;    // row width in floats (multiple of 4)
     int SP;    // padded lattice row (multiple of 8)
-    int perm;  // rows in the store order of the kernel with 2^perm states per lane (spill_col); 0: in state order
+    int perm;  // != 0: PACKED rows in the store order of the kernel with 2^perm states per lane (spill_col); 0: f64, in state order
     int modeB; // 1: rows indexed by class, 0: by label position
     size_t off_lse, off_rows, total_floats;  // float offsets
-    size_t off_dbl;  // float offset of the f64 block: alpha[B][T][SP] | beta_rev[B][T][SP] | nll2[B]
+    size_t off_dbl;  // float offset of alpha[B][T][SP] (f64 or packed words), 16-byte aligned like the next two
+    size_t off_beta, off_nll2;   // beta_rev[B][T][SP], nll2[B] (f64)
     size_t off_aux;  // float offset of the aux f64 block (see ctc_dims)
     size_t total_bytes;
 };
@@ -105,7 +123,7 @@ static CtcDims ctc_dims(int T, int B, int V, int Lmax) {
     d.modeB = V <= Lmax + 1;
     d.RW = (int)align_up((size_t)(d.modeB ? V : Lmax + 1), 4);
     const int S = 2 * Lmax + 1;
-    d.perm = (S > 256 && S <= kSingleWaveMaxS) ? 3 : 0;   // measured: no gain at four states per lane
+    d.perm = S > kSingleWaveMaxS ? 0 : S > 512 ? 4 : S > 256 ? 3 : 0;   // measured: no gain at four states per lane
     // permuted rows and the lattices of two states per lane: every lane has its columns (pitch 64 x states per lane),
     // so the recursion wave's row pointer is one scalar walked by a scalar stride
     d.SP = d.perm ? 64 << d.perm : S <= 128 ? 128 : (int)align_up((size_t)S, 8);
@@ -113,8 +131,10 @@ static CtcDims ctc_dims(int T, int B, int V, int Lmax) {
     d.off_lse = o; o += align_up((size_t)B * T, 4);
     d.off_rows = o; o += (size_t)B * T * d.RW;
     o = align_up(o, 4);
-    d.off_dbl = o;
-    o += 2 * ((size_t)2 * B * T * d.SP + B);  // doubles, counted in floats
+    const size_t lat = align_up((size_t)B * T * d.SP * (d.perm ? 1 : 2), 4);   // one lattice block, in floats
+    d.off_dbl = o; o += lat;
+    d.off_beta = o; o += lat;
+    d.off_nll2 = o; o += align_up((size_t)2 * B, 4);
     d.off_aux = o;                            // single-wave lattice kernel: per (dir, b) a dummy spill
     o += 2 * ((size_t)2 * B * (kAuxDummy + T / kRescale + 2));   // row (kAuxDummy doubles) and the scale E after each block
     d.total_floats = o;
@@ -718,7 +738,7 @@ __global__ __launch_bounds__(kLat1Threads) void ctc_lattice1_kernel(
                            (int)(threadIdx.x & 63));
         return;
     }
-    constexpr int TB = 64 / NS;   // frames per chunk
+    constexpr int TB = NS == 16 ? kRescale : 64 / NS;   // frames per chunk (at least one rescale block)
     constexpr int PW = 64 * NS;   // positions per frame
     constexpr int NK = NS / 2;    // labels per lane
     constexpr int HF = TB / H;    // frames per helper wave and chunk
@@ -726,7 +746,7 @@ __global__ __launch_bounds__(kLat1Threads) void ctc_lattice1_kernel(
     // emissions as [buffer][frame][state pair][lane][2]: a lane's pairs lie 1 KB apart, so every 16-byte read or write
     // of a wave is one contiguous KB (lane * NS doubles apart, the reads of four / eight states per lane hit the same
     // banks two / four times over)
-    __shared__ __attribute__((aligned(16))) double s_y[2][TB][PW];   // 64 KB
+    __shared__ __attribute__((aligned(16))) double s_y[2][TB][PW];   // 64 KB (128 KB at sixteen states per lane)
     __shared__ int s_rep[64];
     __shared__ double s_fin[2];
 
@@ -846,7 +866,10 @@ __global__ __launch_bounds__(kLat1Threads) void ctc_lattice1_kernel(
     // ---------------------------------------------------------------------- recursion wave
     // the serial chain outranks the streaming waves of the dense half that may share its SIMD
     __builtin_amdgcn_s_setprio(3);
-    double* out = (dir ? beta_rev : alpha) + (int64_t)b * T * SP;
+    constexpr bool kPack = NS >= 8;   // four-byte states (lat_pack)
+    constexpr int kEsz = kPack ? 4 : 8;
+    char* outb = reinterpret_cast<char*>(dir ? beta_rev : alpha) + (int64_t)b * T * SP * kEsz;
+    double* out = reinterpret_cast<double*>(outb);
     // a(-1) = delta(position 0): one step of the general recurrence then yields the CTC start
     // condition (positions 0 and 1 take their emission, everything else 0)
     double a[NS];
@@ -860,18 +883,19 @@ __global__ __launch_bounds__(kLat1Threads) void ctc_lattice1_kernel(
     const int aux_stride = kAuxDummy + T / kRescale + 2;
     double* aux_b = aux + ((int64_t)dir * B + b) * aux_stride;
     double* ecum = aux_b + kAuxDummy;
-    constexpr bool kPerm = NS == 8;   // spill_col order
     constexpr bool kAllLanes = NS != 4;   // the row pitch is 64 NS (ctc_dims): every lane has its columns
     const bool spill_ok = kAllLanes || lane * NS < SP;
     // row pointer of the frame being written: walks forward (alpha) or backward (beta) by one row
-    double* orow = spill_ok ? out + (int64_t)(dir ? Tb - 1 : 0) * SP + lane * (kPerm ? 2 : NS) : aux_b + lane * NS;
+    double* orow = spill_ok ? out + (int64_t)(dir ? Tb - 1 : 0) * SP + lane * NS : aux_b + lane * NS;   // NS == 4 only
     const int64_t ostep = spill_ok ? (dir ? -(int64_t)SP : (int64_t)SP) : 0;
     // kAllLanes: buffer stores -- the utterance's rows behind one descriptor, the row as a scalar byte offset walked by
     // scalar adds, the lane's column as a fixed vector offset: no vector instruction per frame goes into addressing
-    const auto orsrc = __builtin_amdgcn_make_buffer_rsrc((void*)out, 0, (int)((int64_t)T * SP * 8), 0x00020000);
-    int osoff = (dir ? Tb - 1 : 0) * SP * 8;
-    const int ostep_b = (dir ? -SP : SP) * 8;
-    const int loff = lane * (kPerm ? 16 : NS * 8);
+    const auto orsrc = __builtin_amdgcn_make_buffer_rsrc((void*)outb, 0, (int)((int64_t)T * SP * kEsz), 0x00020000);
+    int osoff = (dir ? Tb - 1 : 0) * SP * kEsz;
+    const int ostep_b = (dir ? -SP : SP) * kEsz;
+    // lanes whose states all lie beyond the utterance's lattice store nothing: their offset is out of the descriptor's
+    // range and the hardware drops the lanes (the consumers read columns < S only)
+    const int loff = (kPack && lane * NS >= S) ? 0x7F000000 : lane * 16;
     auto step = [&](const double (&yq)[NS]) {
         const double p1 = lane_shr1(a[NS - 1]);
         double n_[NS];
@@ -887,16 +911,24 @@ __global__ __launch_bounds__(kLat1Threads) void ctc_lattice1_kernel(
 #pragma unroll
         for (int j = 0; j < NS; ++j) a[j] = n_[j];
     };
-    auto spill = [&]() {   // one vector-memory op per lane and frame (NS == 2)
+    auto spill = [&]() {   // one vector-memory op per lane and frame (NS == 2), NS / 4 of them packed
+        using u4 = __attribute__((ext_vector_type(4))) unsigned;
+        if constexpr (kPack) {
 #pragma unroll
-        for (int j = 0; j < NS; j += 2) {
-            if constexpr (kAllLanes) {
-                using d2 = __attribute__((ext_vector_type(2))) double;
-                using u4 = __attribute__((ext_vector_type(4))) unsigned;
-                const d2 v = {a[j], a[j + 1]};
-                __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u4, v), orsrc, loff + (kPerm ? j * 512 : j * 8), osoff, 0);
-            } else
-                *reinterpret_cast<double2*>(orow + j) = make_double2(a[j], a[j + 1]);
+            for (int j = 0; j < NS; j += 4) {
+                const u4 v = {lat_pack(a[j]), lat_pack(a[j + 1]), lat_pack(a[j + 2]), lat_pack(a[j + 3])};
+                __builtin_amdgcn_raw_buffer_store_b128(v, orsrc, loff + j * 256, osoff, 0);
+            }
+        } else {
+#pragma unroll
+            for (int j = 0; j < NS; j += 2) {
+                if constexpr (kAllLanes) {
+                    using d2 = __attribute__((ext_vector_type(2))) double;
+                    const d2 v = {a[j], a[j + 1]};
+                    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u4, v), orsrc, loff + j * 8, osoff, 0);
+                } else
+                    *reinterpret_cast<double2*>(orow + j) = make_double2(a[j], a[j + 1]);
+            }
         }
         if constexpr (kAllLanes) osoff += ostep_b;
         else orow += ostep;
@@ -915,9 +947,11 @@ __global__ __launch_bounds__(kLat1Threads) void ctc_lattice1_kernel(
             for (int j = 1; j < NS; ++j) mh = max(mh, __double2hiint(a[j]));
             const int e = (wave_max_i(mh) >> 20) & 0x7FF;
             const int dp = e ? e - (1023 + kTopBits) : 0;
+            // the block's emissions: all eight frames up front, or (sixteen states per lane: 32 registers a frame) kAhead
+            // frames ahead of the one being computed
+            constexpr int kAhead = NS == 16 ? 3 : kRescale;
             double y[kRescale][NS];
-#pragma unroll
-            for (int q = 0; q < kRescale; ++q) {
+            auto fetch_y = [&](int q) {
                 const double* src = &s_y[c & 1][k0 + q][lane * 2];
 #pragma unroll
                 for (int j = 0; j < NS; j += 2) {
@@ -925,13 +959,19 @@ __global__ __launch_bounds__(kLat1Threads) void ctc_lattice1_kernel(
                     y[q][j] = v.x;
                     y[q][j + 1] = v.y;
                 }
-            }
+            };
 #pragma unroll
-            for (int j = 0; j < NS; ++j) y[kRescale - 1][j] = ldexp(y[kRescale - 1][j], -dp);
+            for (int q = 0; q < kAhead; ++q) fetch_y(q);
 #pragma unroll
             for (int q = 0; q < kRescale; ++q) {
+                if (q + kAhead < kRescale) fetch_y(q + kAhead);
+                if (q == kRescale - 1) {
+#pragma unroll
+                    for (int j = 0; j < NS; ++j) y[q][j] = ldexp(y[q][j], -dp);
+                }
                 step(y[q]);
                 spill();
+                if constexpr (NS == 16) __builtin_amdgcn_sched_barrier(0);   // keeps the fetches where they are written
             }
             E += dp;
             ecum[i / kRescale] = (double)E;   // the scale of the block's last frame and of the next block's first seven
@@ -974,12 +1014,12 @@ __global__ __launch_bounds__(256) void ctc_grad_kernel(
     const float* __restrict__ logits, int64_t st, int64_t sb, const int64_t* __restrict__ labels,
     int label_stride, const int32_t* __restrict__ in_len, const int32_t* __restrict__ lab_len,
     int T, int B, int V, int blank, int Lmax, int RW, int SP, int modeB,
-    const float* __restrict__ lse2, const float* __restrict__ rows, const double* __restrict__ alpha,
-    const double* __restrict__ beta_rev, const double* __restrict__ aux,
+    const float* __restrict__ lse2, const float* __restrict__ rows, const void* __restrict__ alpha,
+    const void* __restrict__ beta_rev, const double* __restrict__ aux,
     const double* __restrict__ nll2d, const float* __restrict__ nll, float grad_scale,
     G* __restrict__ grad, float* __restrict__ loss, int perm) {
     extern __shared__ __attribute__((aligned(16))) float s_occ[];  // [waves][V]
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);   // uniform: row pointers stay scalar
     const int wpb = blockDim.x >> 6;
 
     if (blockIdx.x == 0 && wave == 0 && loss) {
@@ -1015,8 +1055,7 @@ __global__ __launch_bounds__(256) void ctc_grad_kernel(
         const int L = min(max(lab_len[b], 0), Lmax);
         const int S = 2 * L + 1;
         const float scale = grad_scale / ((float)B * (float)max(L, 1));
-        const double* arow = alpha + ((int64_t)b * T + t) * SP;
-        const double* brow = beta_rev + ((int64_t)b * T + t) * SP;
+        const int64_t lrow_i = (int64_t)b * T + t;
         // 2^gexp * alpha_hat * beta_hat / y = the state posterior; slot SP-1 of a row is its scale E
         // (multi-wave lattices) or, for the single-wave kernel, Ecum[block] of its aux block
         double gexp = nll2d[b];
@@ -1026,7 +1065,7 @@ __global__ __launch_bounds__(256) void ctc_grad_kernel(
             if (ka >= 0) gexp += aux[(int64_t)b * aux_stride + kAuxDummy + ka];
             if (kb >= 0) gexp += aux[((int64_t)B + b) * aux_stride + kAuxDummy + kb];
         } else {
-            gexp += arow[SP - 1] + brow[SP - 1];
+            gexp += lat_load(alpha, lrow_i, SP, SP - 1, 0) + lat_load(beta_rev, lrow_i, SP, SP - 1, 0);
         }
         const float* lrow = rows + ((int64_t)b * T + t) * RW;
         const int64_t* lab = labels + (int64_t)b * label_stride;
@@ -1041,7 +1080,8 @@ __global__ __launch_bounds__(256) void ctc_grad_kernel(
             const double gq = gexp - (double)lrow[ri];
             const double gn = floor(gq);
             int xa, xb;
-            const double ma = frexp(arow[spill_col(s, perm)], &xa), mb = frexp(brow[spill_col(S - 1 - s, perm)], &xb);
+            const double ma = frexp(lat_load(alpha, lrow_i, SP, spill_col(s, perm), perm), &xa);
+            const double mb = frexp(lat_load(beta_rev, lrow_i, SP, spill_col(S - 1 - s, perm), perm), &xb);
             const double pr = ma * mb * (double)__builtin_amdgcn_exp2f((float)(gq - gn));
             const double ge = fmax(fmin(gn + (double)(xa + xb), 4000.0), -4000.0);
             const float gam = (float)ldexp(pr, (int)ge);
@@ -1081,16 +1121,25 @@ __global__ __launch_bounds__(256) void ctc_grad_kernel(
 // log-prob values of all kR frames are in flight together (a single row per wave left the kernel latency-bound:
 // 26 us for 46 MB), and the occupancies are summed in compact per-frame slots (slot 0 = blank, slot 1 + k = one
 // label position that carries position k's class), so nothing V-sized is cleared.
-// NI = lattice states per lane (S <= 64 NI).
-template <typename G, int NI, int kR>
+// NI = lattice states per lane (S <= 64 NI); NI >= 8: packed rows (lat_pack), the lanes take the states in the
+// producer's store order, so that every load of the wave is 256 contiguous bytes of an alpha row.
+// kDense (vocabularies of <= 64 classes with class-indexed rows, the reference's characters): the slots are the
+// classes themselves and the wave writes the frame's WHOLE gradient row, p - occupancy for every class and zeros
+// beyond the utterance's length -- there is no dense half, the logits are not read again.
+template <int NI, bool kDense>
+constexpr int kSparseGroups = 1;   // groups of kR frames per item, the next group's loads in flight behind the current one's arithmetic (measured: no gain at the sizes this kernel still serves; ctc_char_grad_kernel is the pipelined form)
+
+template <typename G, int NI, int kR, bool kDense>
 __global__ __launch_bounds__(256) void ctc_sparse_kernel(
     int64_t st, int64_t sb, const int64_t* __restrict__ labels, int label_stride,
     const int32_t* __restrict__ in_len, const int32_t* __restrict__ lab_len, int T, int B, int V, int blank,
-    int Lmax, int RW, int SP, int modeB, const float* __restrict__ rows, const double* __restrict__ alpha,
-    const double* __restrict__ beta_rev, const double* __restrict__ aux, const double* __restrict__ nll2d,
+    int Lmax, int RW, int SP, int modeB, const float* __restrict__ rows, const void* __restrict__ alpha,
+    const void* __restrict__ beta_rev, const double* __restrict__ aux, const double* __restrict__ nll2d,
     const float* __restrict__ nll, float grad_scale, G* __restrict__ grad, float* __restrict__ loss, int perm) {
-    extern __shared__ __attribute__((aligned(16))) float s_dyn[];  // per wave: first[V] (int) | acc[kR][AL]
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    extern __shared__ __attribute__((aligned(16))) float s_dyn[];  // per wave: first[V] (int) | acc[kR][AL]; kDense: acc[kR][V]
+    constexpr bool kPack = NI >= 8;
+    using LT = typename std::conditional<kPack, uint32_t, double>::type;
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);   // uniform: row pointers stay scalar
     const int wpb = blockDim.x >> 6;
 
     if (blockIdx.x == 0 && wave == 0 && loss) {
@@ -1101,128 +1150,357 @@ __global__ __launch_bounds__(256) void ctc_sparse_kernel(
     }
     if (!grad) return;
 
-    const int AL = Lmax + 2;
-    int* first = reinterpret_cast<int*>(s_dyn + (size_t)wave * (V + kR * AL));
-    float* acc = reinterpret_cast<float*>(first + V);
-    const int groups = (T + kR - 1) / kR;
+    const int AL = kDense ? V : Lmax + 2;
+    int* first = reinterpret_cast<int*>(s_dyn + (size_t)wave * ((kDense ? 0 : V) + kR * AL));
+    float* acc = reinterpret_cast<float*>(first + (kDense ? 0 : V));
+    // One item = kG groups of kR consecutive frames of one utterance.  kG > 1 (whole-row mode at eight and sixteen
+    // states per lane, where an item's set-up -- up to sixteen label gathers per lane -- and its load latency were what
+    // the kernel spent its time on): the classes are set up once, and group g + 1's alpha / beta / log-prob loads are
+    // in flight while group g is computed.
+    constexpr int kG = kSparseGroups<NI, kDense>;
+    const int groups = (T + kR * kG - 1) / (kR * kG);
     const int64_t nitems = (int64_t)B * groups;
     const int aux_stride = kAuxDummy + T / kRescale + 2;
+    // state of (lane, i).  Packed rows are [NI / 4 planes][64 producer lanes][4]: load i of the wave takes plane
+    // i % (NI / 4) of the producer lanes 16 (i / (NI / 4)) .. + 15, four consecutive states per producer lane
+    auto state_of = [&](int i) {
+        if constexpr (kPack) return (((i / (NI / 4)) * 16 + (lane >> 2)) * NI) + (i % (NI / 4)) * 4 + (lane & 3);
+        else return lane + 64 * i;
+    };
     for (int64_t it = (int64_t)blockIdx.x * wpb + wave; it < nitems; it += (int64_t)gridDim.x * wpb) {
-        const int b = (int)(it / groups), t0 = (int)(it % groups) * kR;
+        const int b = (int)(it / groups), t0 = (int)(it % groups) * (kR * kG);
         const int Tb = min(max(in_len[b], 0), T);
-        if (t0 >= Tb) continue;
+        auto zero_rows = [&](int ta, int te) {   // rows beyond the utterance's length are zeros
+            for (int t = ta; t < min(te, T); ++t)
+                if (lane < V) Elem<G>::st(grad + (int64_t)t * st + b * sb + lane, 0.f);
+        };
+        if (t0 >= Tb) {
+            if constexpr (kDense) zero_rows(t0, t0 + kR * kG);
+            continue;
+        }
         const int L = min(max(lab_len[b], 0), Lmax);
         const int S = 2 * L + 1;
         const float scale = grad_scale / ((float)B * (float)max(L, 1));
         const int64_t* lab = labels + (int64_t)b * label_stride;
+        const double gbase = nll2d[b];
 
-        // ---- every load of the item is issued before anything waits: classes, then kR frames of alpha / beta / log-probs
+        // ---- every load of a group is issued before anything waits: classes, then kR frames of alpha / beta / log-probs
         int cls[NI], ri[NI];
 #pragma unroll
         for (int i = 0; i < NI; ++i) {
-            const int s_ = lane + 64 * i;
-            cls[i] = blank;
-            if ((s_ & 1) && s_ < S) cls[i] = min(max((int)lab[(s_ - 1) >> 1], 0), V - 1);
+            // one unconditional gather per state (a load under a per-lane condition compiles to a branch and a full wait each)
+            const int s_ = state_of(i);
+            const bool has = (s_ & 1) && s_ < S;
+            const int c = L > 0 ? (int)lab[has ? (s_ - 1) >> 1 : 0] : blank;
+            cls[i] = has ? min(max(c, 0), V - 1) : blank;
         }
-        double av[kR][NI], bv[kR][NI], gexp[kR];
-        const double gbase = nll2d[b];
+        LT avn[kR][NI], bvn[kR][NI];
+        double gexpn[kR];
+        float lrn[kDense ? 1 : kR][kDense ? 1 : NI], palln[kR];   // kDense: log2-prob of class `lane`, the states' by shuffle
+        auto issue_lattice = [&](int tg) {
 #pragma unroll
-        for (int q = 0; q < kR; ++q) {
-            const int t = min(t0 + q, Tb - 1);
-            const double* arow = alpha + ((int64_t)b * T + t) * SP;
-            const double* brow = beta_rev + ((int64_t)b * T + t) * SP;
+            for (int q = 0; q < kR; ++q) {
+                const int t = min(tg + q, Tb - 1);
+                const LT* arow = reinterpret_cast<const LT*>(alpha) + ((int64_t)b * T + t) * SP;
+                const LT* brow = reinterpret_cast<const LT*>(beta_rev) + ((int64_t)b * T + t) * SP;
 #pragma unroll
-            for (int i = 0; i < NI; ++i) {
-                const int s_ = min(lane + 64 * i, S - 1);
-                av[q][i] = arow[spill_col(s_, perm)];
-                bv[q][i] = brow[spill_col(S - 1 - s_, perm)];
+                for (int i = 0; i < NI; ++i) {
+                    const int s_ = min(state_of(i), S - 1);
+                    avn[q][i] = arow[spill_col(s_, perm)];
+                    bvn[q][i] = brow[spill_col(S - 1 - s_, perm)];
+                }
+                // 2^gexp * alpha_hat * beta_hat / y = the state posterior (Ecum of the two rescale blocks, see ctc_grad_kernel)
+                const int ka = (t + 1) / kRescale - 1, kb = (Tb - t) / kRescale - 1;
+                double ge = gbase;
+                if (ka >= 0) ge += aux[(int64_t)b * aux_stride + kAuxDummy + ka];
+                if (kb >= 0) ge += aux[((int64_t)B + b) * aux_stride + kAuxDummy + kb];
+                gexpn[q] = ge;
             }
-            // 2^gexp * alpha_hat * beta_hat / y = the state posterior (Ecum of the two rescale blocks, see ctc_grad_kernel)
-            const int ka = (t + 1) / kRescale - 1, kb = (Tb - t) / kRescale - 1;
-            double ge = gbase;
-            if (ka >= 0) ge += aux[(int64_t)b * aux_stride + kAuxDummy + ka];
-            if (kb >= 0) ge += aux[((int64_t)B + b) * aux_stride + kAuxDummy + kb];
-            gexp[q] = ge;
-        }
-        float lr[kR][NI];
+        };
+        auto issue_rows = [&](int tg) {
+#pragma unroll
+            for (int q = 0; q < kR; ++q) {
+                const float* lrow = rows + ((int64_t)b * T + min(tg + q, Tb - 1)) * RW;
+                if constexpr (kDense) palln[q] = lrow[min(lane, V - 1)];
+                else {
+                    palln[q] = 0.f;
+#pragma unroll
+                    for (int i = 0; i < NI; ++i) lrn[q][i] = lrow[ri[i]];
+                }
+            }
+        };
+        issue_lattice(t0);
 #pragma unroll
         for (int i = 0; i < NI; ++i) {
-            const int s_ = lane + 64 * i;
+            const int s_ = state_of(i);
             ri[i] = modeB ? cls[i] : ((s_ & 1) ? (s_ + 1) >> 1 : 0);
             if (s_ >= S) ri[i] = 0;
         }
-#pragma unroll
-        for (int q = 0; q < kR; ++q) {
-            const float* lrow = rows + ((int64_t)b * T + min(t0 + q, Tb - 1)) * RW;
-#pragma unroll
-            for (int i = 0; i < NI; ++i) lr[q][i] = lrow[ri[i]];
-        }
+        issue_rows(t0);
 
-        // ---- slot of every label position: ONE position of its class (whichever write the LDS ordered last: every
-        // position of the class reads the same survivor; the wave's LDS operations execute in order)
-        __builtin_amdgcn_wave_barrier();   // the previous item's reads of first[] / acc[] are done
-#pragma unroll
-        for (int i = 0; i < NI; ++i) {
-            const int s_ = lane + 64 * i;
-            if ((s_ & 1) && s_ < S) first[cls[i]] = (s_ - 1) >> 1;
-        }
-        __builtin_amdgcn_wave_barrier();
         int slot[NI];
+        if constexpr (kDense) {
 #pragma unroll
-        for (int i = 0; i < NI; ++i) {
-            const int s_ = lane + 64 * i;
-            slot[i] = ((s_ & 1) && s_ < S) ? 1 + first[cls[i]] : 0;
-        }
-        for (int c = lane; c < kR * AL; c += 64) acc[c] = 0.f;
-        __builtin_amdgcn_wave_barrier();
-
-        // ---- posteriors of the kR frames into their slots
-        float blank_acc[kR];
-#pragma unroll
-        for (int q = 0; q < kR; ++q) {
-            blank_acc[q] = 0.f;
+            for (int i = 0; i < NI; ++i) slot[i] = cls[i];
+        } else {
+            // ---- slot of every label position: ONE position of its class (whichever write the LDS ordered last: every
+            // position of the class reads the same survivor; the wave's LDS operations execute in order)
+            __builtin_amdgcn_wave_barrier();   // the previous item's reads of first[] / acc[] are done
 #pragma unroll
             for (int i = 0; i < NI; ++i) {
-                const int s_ = lane + 64 * i;
-                // alpha_hat and beta_hat can each sit ~1000 binary orders below their row maxima where the
-                // posterior peaks: multiply mantissas, add exponents, one ldexp
-                const double gq = gexp[q] - (double)lr[q][i];
-                const double gn = floor(gq);
-                int xa, xb;
-                const double ma = frexp(av[q][i], &xa), mb = frexp(bv[q][i], &xb);
-                const double pr = ma * mb * (double)__builtin_amdgcn_exp2f((float)(gq - gn));
-                const double ge = fmax(fmin(gn + (double)(xa + xb), 4000.0), -4000.0);
-                float gam = (float)ldexp(pr, (int)ge);
-                if (s_ >= S || t0 + q >= Tb) gam = 0.f;
-                if (s_ & 1) {
-                    if (gam != 0.f) atomicAdd(&acc[q * AL + slot[i]], gam);
-                } else {
-                    blank_acc[q] += gam;
+                const int s_ = state_of(i);
+                if ((s_ & 1) && s_ < S) first[cls[i]] = (s_ - 1) >> 1;
+            }
+            __builtin_amdgcn_wave_barrier();
+#pragma unroll
+            for (int i = 0; i < NI; ++i) {
+                const int s_ = state_of(i);
+                slot[i] = ((s_ & 1) && s_ < S) ? 1 + first[cls[i]] : 0;
+            }
+        }
+
+#pragma unroll 1
+        for (int g = 0; g < kG; ++g) {
+            const int tg = t0 + g * kR;
+            if (tg >= T) break;
+            if (tg >= Tb) {   // kG > 1 only: the rest of the item lies beyond the utterance
+                if constexpr (kDense) zero_rows(tg, t0 + kR * kG);
+                break;
+            }
+            LT av[kR][NI], bv[kR][NI];
+            double gexp[kR];
+            float lr[kDense ? 1 : kR][kDense ? 1 : NI], pall[kR];
+#pragma unroll
+            for (int q = 0; q < kR; ++q) {
+                gexp[q] = gexpn[q];
+                pall[q] = palln[q];
+#pragma unroll
+                for (int i = 0; i < NI; ++i) {
+                    av[q][i] = avn[q][i];
+                    bv[q][i] = bvn[q][i];
+                    if constexpr (!kDense) lr[q][i] = lrn[q][i];
+                }
+            }
+            if (kG > 1 && g + 1 < kG && tg + kR < Tb) {
+                issue_lattice(tg + kR);
+                issue_rows(tg + kR);
+            }
+            __builtin_amdgcn_wave_barrier();   // the previous group's reads of acc[] are done
+            for (int c = lane; c < kR * AL; c += 64) acc[c] = 0.f;
+            __builtin_amdgcn_wave_barrier();
+
+            // ---- posteriors of the kR frames into their slots
+            float blank_acc[kR];
+#pragma unroll
+            for (int q = 0; q < kR; ++q) {
+                blank_acc[q] = 0.f;
+#pragma unroll
+                for (int i = 0; i < NI; ++i) {
+                    const int s_ = state_of(i);
+                    float lrv;
+                    if constexpr (kDense) lrv = __shfl(pall[q], cls[i]);
+                    else lrv = lr[q][i];
+                    // alpha_hat and beta_hat can each sit ~1000 binary orders below their row maxima where the
+                    // posterior peaks: multiply mantissas, add exponents, one ldexp
+                    const double gq = gexp[q] - (double)lrv;
+                    const double gn = floor(gq);
+                    int xa, xb;
+                    double ad, bd;
+                    if constexpr (kPack) { ad = lat_unpack(av[q][i]); bd = lat_unpack(bv[q][i]); }
+                    else { ad = av[q][i]; bd = bv[q][i]; }
+                    const double ma = frexp(ad, &xa), mb = frexp(bd, &xb);
+                    const double pr = ma * mb * (double)__builtin_amdgcn_exp2f((float)(gq - gn));
+                    const double ge = fmax(fmin(gn + (double)(xa + xb), 4000.0), -4000.0);
+                    float gam = (float)ldexp(pr, (int)ge);
+                    if (s_ >= S || tg + q >= Tb) gam = 0.f;
+                    if (s_ & 1) {
+                        if (gam != 0.f) atomicAdd(&acc[q * AL + slot[i]], gam);
+                    } else {
+                        blank_acc[q] += gam;
+                    }
+                }
+            }
+#pragma unroll
+            for (int q = 0; q < kR; ++q) blank_acc[q] = wave_sum_dpp(blank_acc[q]);   // kR independent chains
+            if (lane < kR) {
+                float v = blank_acc[0];
+#pragma unroll
+                for (int q = 1; q < kR; ++q) v = (lane == q) ? blank_acc[q] : v;
+                if constexpr (kDense) atomicAdd(&acc[lane * AL + blank], v);   // a label may (wrongly) name the blank class
+                else acc[lane * AL] = v;   // slot 0 is the blank's alone
+            }
+            __builtin_amdgcn_wave_barrier();
+
+            if constexpr (kDense) {
+                // ---- the whole row: class `lane`
+#pragma unroll
+                for (int q = 0; q < kR; ++q) {
+                    if (tg + q >= T) break;
+                    if (lane < V) {
+                        const float gv = tg + q < Tb ? (exp2f(pall[q]) - acc[q * AL + lane]) * scale : 0.f;
+                        Elem<G>::st(grad + (int64_t)(tg + q) * st + b * sb + lane, gv);
+                    }
+                }
+            } else {
+                // ---- overwrite the touched classes (every position of a class stores the same value)
+#pragma unroll
+                for (int q = 0; q < kR; ++q) {
+                    if (tg + q >= Tb) break;
+                    G* g_ = grad + (int64_t)(tg + q) * st + b * sb;
+#pragma unroll
+                    for (int i = 0; i < NI; ++i) {
+                        const int s_ = state_of(i);
+                        if (s_ >= S || (!(s_ & 1) && s_ != 0)) continue;   // one store for the blank class
+                        Elem<G>::st(g_ + cls[i], (exp2f(lr[q][i]) - acc[q * AL + slot[i]]) * scale);
+                    }
                 }
             }
         }
-#pragma unroll
-        for (int q = 0; q < kR; ++q) blank_acc[q] = wave_sum_dpp(blank_acc[q]);   // kR independent chains
-        if (lane < kR) {
-            float v = blank_acc[0];
-#pragma unroll
-            for (int q = 1; q < kR; ++q) v = (lane == q) ? blank_acc[q] : v;
-            acc[lane * AL] = v;   // slot 0 is the blank's alone
-        }
-        __builtin_amdgcn_wave_barrier();
+    }
+}
 
-        // ---- overwrite the touched classes (every position of a class stores the same value)
-#pragma unroll
-        for (int q = 0; q < kR; ++q) {
-            if (t0 + q >= Tb) break;
-            G* g = grad + (int64_t)(t0 + q) * st + b * sb;
+// K3 for the reference's character vocabulary at eight and sixteen states per lane (V <= 64 classes, class-indexed
+// rows, packed lattices: 15 s and 30 s of characters).  One wave walks kCharFrames consecutive frames of one utterance
+// and writes their WHOLE gradient rows, (p - occupancy) * scale for every class and zeros beyond the utterance's
+// length; there is no dense half and the logits are not read again (p = exp2 of K1's row).  The classes of the lane's
+// states are gathered once per item; a frame's states are taken in two halves, each half's alpha / beta words
+// requested one half-frame ahead of its arithmetic (registers for one frame in flight, four waves per SIMD).  The
+// lanes take the states in the producer's store order: every alpha load of the wave is 256 contiguous bytes.
+constexpr int kCharFrames = 8;
+template <typename G, int NI>
+__global__ __launch_bounds__(256, NI == 16 ? 3 : 4) void ctc_char_grad_kernel(
+    int64_t st, int64_t sb, const int64_t* __restrict__ labels, int label_stride,
+    const int32_t* __restrict__ in_len, const int32_t* __restrict__ lab_len, int T, int B, int V, int blank,
+    int Lmax, int RW, int SP, const float* __restrict__ rows, const uint32_t* __restrict__ alpha,
+    const uint32_t* __restrict__ beta_rev, const double* __restrict__ aux, const double* __restrict__ nll2d,
+    const float* __restrict__ nll, float grad_scale, G* __restrict__ grad, float* __restrict__ loss, int perm) {
+    __shared__ float s_acc[4][128];   // per wave: the classes' occupancies | a dummy slot per lane
+    constexpr int NH = NI / 2, Q = NI / 4;
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);   // uniform: row pointers stay scalar
+    const int wpb = blockDim.x >> 6;
+    if (blockIdx.x == 0 && wave == 0 && loss) {
+        float a_ = 0.f;
+        for (int b = lane; b < B; b += 64) a_ += nll[b] / (float)max(min(lab_len[b], Lmax), 1);
+        a_ = wave_sum(a_);
+        if (lane == 0) loss[0] = a_ / (float)B;
+    }
+    if (!grad) return;
+    float* acc = s_acc[wave];
+    const int groups = (T + kCharFrames - 1) / kCharFrames;
+    const int64_t nitems = (int64_t)B * groups;
+    const int aux_stride = kAuxDummy + T / kRescale + 2;
+    // load i of the wave: plane i % Q of the producer lanes 16 (i / Q) .. + 15, four consecutive states per producer lane
+    auto state_of = [&](int i) { return (((i / Q) * 16 + (lane >> 2)) * NI) + (i % Q) * 4 + (lane & 3); };
+    const int lc = min(lane, V - 1);
+    for (int64_t it = (int64_t)blockIdx.x * wpb + wave; it < nitems; it += (int64_t)gridDim.x * wpb) {
+        const int b = (int)(it / groups), t0 = (int)(it % groups) * kCharFrames;
+        const int Tb = min(max(in_len[b], 0), T);
+        const int te = min(t0 + kCharFrames, Tb);
+        if (t0 < Tb) {
+            const int L = min(max(lab_len[b], 0), Lmax);
+            const int S = 2 * L + 1;
+            const float scale = grad_scale / ((float)B * (float)max(L, 1));
+            const int64_t* lab = labels + (int64_t)b * label_stride;
+            const double gbase = nll2d[b];
+            int cls[NI];
+            uint32_t valid = 0;   // bit i: state_of(i) < S
+            uint32_t boff[NI];   // unsigned 32-bit offsets from wave-uniform row pointers: no 64-bit address registers
 #pragma unroll
             for (int i = 0; i < NI; ++i) {
-                const int s_ = lane + 64 * i;
-                if (s_ >= S || (!(s_ & 1) && s_ != 0)) continue;   // one store for the blank class
-                Elem<G>::st(g + cls[i], (exp2f(lr[q][i]) - acc[q * AL + slot[i]]) * scale);
+                // one unconditional gather per state (a load under a per-lane condition compiles to a branch and a full wait each)
+                const int s_ = state_of(i);
+                const bool has = (s_ & 1) && s_ < S;
+                const int c = L > 0 ? (int)lab[has ? (s_ - 1) >> 1 : 0] : blank;
+                // blank lanes: the blank class (for its log-prob); label lanes: the label's class, or beyond S a slot of
+                // the lane's own, so no two lanes ever meet on an occupancy slot they do not share
+                cls[i] = (s_ & 1) ? (has ? min(max(c, 0), V - 1) : 64 + lane) : blank;
+                valid |= (s_ < S ? 1u : 0u) << i;
+                boff[i] = (uint32_t)spill_col(max(S - 1 - s_, 0), perm);
+            }
+            const uint32_t* abase = alpha + (int64_t)b * T * SP;
+            const uint32_t* bbase = beta_rev + (int64_t)b * T * SP;
+            const float* rbase = rows + (int64_t)b * T * RW;
+            const uint32_t ulane = (uint32_t)lane, ulc = (uint32_t)lc;
+            uint32_t a0[NH], b0[NH], a1[NH], b1[NH];
+            // states beyond S read columns nobody wrote: whatever they hold is discarded below
+            auto issue = [&](int t, int h, uint32_t (&a)[NH], uint32_t (&bb)[NH]) {
+                const uint32_t* ar = abase + (int64_t)t * SP;
+                const uint32_t* br = bbase + (int64_t)t * SP;
+#pragma unroll
+                for (int k = 0; k < NH; ++k) {
+                    const int i = h * NH + k;
+                    a[k] = ar[ulane + (uint32_t)((i % Q) * 256 + (i / Q) * 64)];
+                    bb[k] = br[boff[i]];
+                }
+            };
+            float blank_acc = 0.f, pall = 0.f, gfrac = 0.f;
+            int gint = 0;
+            const bool odd = lane & 1;   // label states: the state's parity is the lane's
+            // The posterior 2^gexp * alpha_hat * beta_hat / y of a state in 32-bit arithmetic on the packed words:
+            // mantissas as floats in [1, 2) (21 bits + the half-step of lat_unpack), multiplied; exponents as integers;
+            // gexp = gint + gfrac split once per frame, the row's log2-prob into floor and fraction exactly; one v_exp
+            // of a fraction in (-1, 1) and one v_ldexp.  Denormal and zero states (biased exponent 0) count as zero.
+            auto half = [&](int h, const uint32_t (&a)[NH], const uint32_t (&bb)[NH]) {
+                float gam[NH];
+#pragma unroll
+                for (int k = 0; k < NH; ++k) {
+                    const int i = h * NH + k;
+                    int c = cls[i];
+                    asm volatile("" : "+v"(c));   // addresses derived from the class are formed here, not kept per state across the frame loop
+                    const float lrv = __shfl(pall, c);
+                    const float li = floorf(lrv);
+                    const float sfr = gfrac - (lrv - li);
+                    const uint32_t wa = a[k], wb = bb[k];
+                    const float ma = __uint_as_float(0x3F800002u | ((wa & 0x1FFFFFu) << 2));
+                    const float mb = __uint_as_float(0x3F800002u | ((wb & 0x1FFFFFu) << 2));
+                    const int ea = (int)(wa >> 21), eb = (int)(wb >> 21);
+                    const int e = min(max(ea + eb + (gint - 2046 - (int)li), -300), 300);
+                    float g_ = ldexpf(ma * mb * __builtin_amdgcn_exp2f(sfr), e);
+                    if (ea == 0 || eb == 0 || !((valid >> i) & 1u)) g_ = 0.f;
+                    gam[k] = g_;
+                }
+                if (odd) {
+#pragma unroll
+                    for (int k = 0; k < NH; ++k) {
+                        const int i = h * NH + k;
+                        if (gam[k] != 0.f) atomicAdd(&acc[cls[i]], gam[k]);
+                    }
+                } else {
+#pragma unroll
+                    for (int k = 0; k < NH; ++k) blank_acc += gam[k];
+                }
+            };
+            issue(t0, 0, a0, b0);
+            float palln = (rbase + (int64_t)t0 * RW)[ulc];
+#pragma unroll 1
+            for (int t = t0; t < te; ++t) {
+                issue(t, 1, a1, b1);
+                pall = palln;
+                palln = (rbase + (int64_t)min(t + 1, te - 1) * RW)[ulc];
+                // 2^gexp * alpha_hat * beta_hat / y = the state posterior (Ecum of the two rescale blocks, see ctc_grad_kernel)
+                const int ka = (t + 1) / kRescale - 1, kb = (Tb - t) / kRescale - 1;
+                double gexp = gbase;
+                if (ka >= 0) gexp += aux[(int64_t)b * aux_stride + kAuxDummy + ka];
+                if (kb >= 0) gexp += aux[((int64_t)B + b) * aux_stride + kAuxDummy + kb];
+                const double gfl = floor(gexp);
+                gint = (int)gfl;
+                gfrac = (float)(gexp - gfl);
+                __builtin_amdgcn_wave_barrier();   // the previous frame's reads of acc[] are done
+                acc[lane] = 0.f;
+                __builtin_amdgcn_wave_barrier();
+                blank_acc = 0.f;
+                half(0, a0, b0);
+                if (t + 1 < te) issue(t + 1, 0, a0, b0);
+                half(1, a1, b1);
+                blank_acc = wave_sum_dpp(blank_acc);
+                if (lane == 0) atomicAdd(&acc[blank], blank_acc);   // a label may (wrongly) name the blank class
+                __builtin_amdgcn_wave_barrier();
+                if (lane < V) Elem<G>::st(grad + (int64_t)t * st + b * sb + lane, (exp2f(pall) - acc[lane]) * scale);
             }
         }
+        // rows beyond the utterance's length are zeros
+        for (int t = max(t0, Tb); t < min(t0 + kCharFrames, T); ++t)
+            if (lane < V) Elem<G>::st(grad + (int64_t)t * st + b * sb + lane, 0.f);
     }
 }
 
@@ -1237,8 +1515,8 @@ static void launch_lattice(const CtcDims& d, float* ws, const int64_t* labels, i
     if (TB < kRescale) TB = kRescale;
     hipLaunchKernelGGL((ctc_lattice_kernel<W, NS>), dim3(d.B, 2), dim3(64 * W), 0, s,
                        ws + d.off_rows, labels, label_stride, in_len, lab_len, d.T, d.V, blank,
-                       d.Lmax, d.RW, d.SP, d.modeB, TB, dbl, dbl + (size_t)d.B * d.T * d.SP,
-                       dbl + (size_t)2 * d.B * d.T * d.SP, nll);
+                       d.Lmax, d.RW, d.SP, d.modeB, TB, dbl, reinterpret_cast<double*>(ws + d.off_beta),
+                       reinterpret_cast<double*>(ws + d.off_nll2), nll);
 }
 
 }  // namespace sp
@@ -1274,6 +1552,8 @@ extern "C" int sp_ctc_fwd_bwd(const float* logits, int64_t stride_t, int64_t str
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
     float* ws = reinterpret_cast<float*>(workspace);
     const double* dbl = reinterpret_cast<const double*>(ws + d.off_dbl);
+    const double* dblb = reinterpret_cast<const double*>(ws + d.off_beta);
+    const double* dbln2 = reinterpret_cast<const double*>(ws + d.off_nll2);
     const int64_t nrows = (int64_t)T * B;
     const int row_blocks = (int)((nrows + 3) / 4 > 8192 ? 8192 : (nrows + 3) / 4);
 
@@ -1302,7 +1582,10 @@ extern "C" int sp_ctc_fwd_bwd(const float* logits, int64_t stride_t, int64_t str
     // a CU would finish last); the sparse half follows.  Only while the lattice leaves at least half of the chip:
     // larger batches run the lattice two workgroups to a CU and the fused gradient kernel on the whole chip after it.
     const bool have_grad = grad && T > 0;
-    const bool split = have_grad && S <= kSingleWaveMaxS && 4 * B <= kCUs;
+    // Small vocabularies with class-indexed rows (the reference's 28 characters + blank): the sparse-half kernel writes
+    // whole gradient rows (kDense), at any batch size and any single-wave lattice; no dense half, no fused kernel.
+    const bool small = have_grad && d.modeB && V <= 64 && S <= kSingleWaveMaxS;
+    const bool split = have_grad && !small && S <= kSplitMaxS && 4 * B <= kCUs;
     // How many: the dense half should END with the lattice, not race it -- with all free CUs streaming, the recursion
     // lost 10 % (32 x 751: 41.8 us with 96 dense workgroups, 43.8 with 160, 45.5 with 192) although no streaming wave
     // shares its CUs.  A CU streams ~32 GB/s of rows that the Infinity Cache still holds and ~22 GB/s from HBM; the
@@ -1316,8 +1599,8 @@ extern "C" int sp_ctc_fwd_bwd(const float* logits, int64_t stride_t, int64_t str
         dense_blocks = std::min(dense_blocks, std::max(32, (int)(1.3 * bytes / (t_lat * per_cu)) + 1));
     }
 #define SP_LAT1_ARGS ws + d.off_rows, labels, label_stride, input_lengths, label_lengths, T, V, blank, max_label_len, d.RW, \
-                     d.SP, d.modeB, dblw, dblw + (size_t)B * T * d.SP, reinterpret_cast<double*>(ws + d.off_aux),           \
-                     dblw + (size_t)2 * B * T * d.SP, nll, B, logits, stride_t, stride_b, ws + d.off_lse, grad_scale, grad,  \
+                     d.SP, d.modeB, dblw, reinterpret_cast<double*>(ws + d.off_beta), reinterpret_cast<double*>(ws + d.off_aux), \
+                     reinterpret_cast<double*>(ws + d.off_nll2), nll, B, logits, stride_t, stride_b, ws + d.off_lse, grad_scale, grad,  \
                      grad_dtype == SP_BF16 ? 1 : (grad_dtype == SP_F16 ? 2 : 0)
 #define SP_LAT1(NS, H)                                                                                                       \
     hipLaunchKernelGGL((ctc_lattice1_kernel<NS, H>), dim3(2 * B + dense_blocks), dim3(split ? kLat1Threads : 64 * (1 + H)),  \
@@ -1325,12 +1608,12 @@ extern "C" int sp_ctc_fwd_bwd(const float* logits, int64_t stride_t, int64_t str
     if (S <= 128) {
         // four helper waves when the workgroup has a CU to itself (two could not keep up with the recursion: 43.4 ->
         // 39.7 us at 32 x 751 x 1000); two where two workgroups share a CU's registers
-        if (split) SP_LAT1(2, 4);
+        if (split || (small && 2 * B <= kCUs)) SP_LAT1(2, 4);
         else SP_LAT1(2, 2);
     }
     else if (S <= 256) SP_LAT1(4, 4);
-    else if (S <= kSingleWaveMaxS) SP_LAT1(8, 4);   // 15 s of characters (L <= 255): eight states per lane, still no barrier per frame
-    else if (S <= 1024) launch_lattice<4, 4>(d, ws, labels, label_stride, input_lengths, label_lengths, blank, nll, s);
+    else if (S <= 512) SP_LAT1(8, 4);   // 15 s of characters (L <= 255): eight states per lane, still no barrier per frame
+    else if (S <= kSingleWaveMaxS) SP_LAT1(16, 4);   // 30 s of characters (L <= 511): sixteen states per lane
     else launch_lattice<4, 8>(d, ws, labels, label_stride, input_lengths, label_lengths, blank, nll, s);
 #undef SP_LAT1
 #undef SP_LAT1_ARGS
@@ -1341,34 +1624,64 @@ extern "C" int sp_ctc_fwd_bwd(const float* logits, int64_t stride_t, int64_t str
         const int gb = have_grad ? row_blocks : 1;
         const size_t lds = (size_t)4 * V * sizeof(float);
         const double* auxp = S <= kSingleWaveMaxS ? reinterpret_cast<const double*>(ws + d.off_aux) : nullptr;
-        if (split) {
+        if (split || small) {
 #define SP_GRAD_ARGS stride_t, stride_b, labels, label_stride, input_lengths, label_lengths, T, B, V, blank, max_label_len,  \
-                     d.RW, d.SP, d.modeB, ws + d.off_rows, dbl, dbl + (size_t)B * T * d.SP, auxp,                            \
-                     dbl + (size_t)2 * B * T * d.SP, nll, grad_scale
+                     d.RW, d.SP, d.modeB, ws + d.off_rows, dbl, dblb, auxp, dbln2, nll, grad_scale
 #define SP_SPARSE(NI, R)                                                                                                     \
     do {                                                                                                                     \
-        const int64_t items = (int64_t)B * ((T + R - 1) / R);                                                                \
+        const int fpi = R * kSparseGroups<NI, DENSE>;                                                                         \
+        const int64_t items = (int64_t)B * ((T + fpi - 1) / fpi);                                                            \
         const int sg = (int)std::min<int64_t>((items + 3) / 4, 8192);                                                        \
-        const size_t sl = (size_t)4 * (V + R * (max_label_len + 2)) * sizeof(float);                                         \
+        const size_t sl = (size_t)4 * (DENSE ? R * V : V + R * (max_label_len + 2)) * sizeof(float);                         \
         if (grad_dtype == SP_BF16)                                                                                           \
-            hipLaunchKernelGGL((ctc_sparse_kernel<__hip_bfloat16, NI, R>), dim3(sg), dim3(256), sl, s, SP_GRAD_ARGS,         \
-                               (__hip_bfloat16*)grad, loss, d.perm);                                                                 \
+            hipLaunchKernelGGL((ctc_sparse_kernel<__hip_bfloat16, NI, R, DENSE>), dim3(sg), dim3(256), sl, s, SP_GRAD_ARGS,  \
+                               (__hip_bfloat16*)grad, loss, d.perm);                                                         \
         else if (grad_dtype == SP_F16)                                                                                       \
-            hipLaunchKernelGGL((ctc_sparse_kernel<__half, NI, R>), dim3(sg), dim3(256), sl, s, SP_GRAD_ARGS,                 \
+            hipLaunchKernelGGL((ctc_sparse_kernel<__half, NI, R, DENSE>), dim3(sg), dim3(256), sl, s, SP_GRAD_ARGS,          \
                                (__half*)grad, loss, d.perm);                                                                 \
         else                                                                                                                 \
-            hipLaunchKernelGGL((ctc_sparse_kernel<float, NI, R>), dim3(sg), dim3(256), sl, s, SP_GRAD_ARGS, (float*)grad,    \
-                               loss, d.perm);                                                                                     \
+            hipLaunchKernelGGL((ctc_sparse_kernel<float, NI, R, DENSE>), dim3(sg), dim3(256), sl, s, SP_GRAD_ARGS,           \
+                               (float*)grad, loss, d.perm);                                                                  \
     } while (0)
-            if (S <= 128) SP_SPARSE(2, 2);   // measured at 32 x 751 x 1000: 19.9 / 18.5 / 21.4 us at 1 / 2 / 4 frames per wave
-            else if (S <= 256) SP_SPARSE(4, 2);
-            else SP_SPARSE(8, 1);   // registers: one frame per wave at eight states per lane (47 against 60 us)
+#define SP_CHAR(NI)                                                                                                          \
+    do {                                                                                                                     \
+        const int64_t items = (int64_t)B * ((T + kCharFrames - 1) / kCharFrames);                                            \
+        const int sg = (int)std::min<int64_t>((items + 3) / 4, 16384);                                                       \
+        const uint32_t* al = reinterpret_cast<const uint32_t*>(dbl);                                                         \
+        const uint32_t* be = reinterpret_cast<const uint32_t*>(dblb);                                                        \
+        if (grad_dtype == SP_BF16)                                                                                           \
+            hipLaunchKernelGGL((ctc_char_grad_kernel<__hip_bfloat16, NI>), dim3(sg), dim3(256), 0, s, SP_CHAR_ARGS,          \
+                               (__hip_bfloat16*)grad, loss, d.perm);                                                         \
+        else if (grad_dtype == SP_F16)                                                                                       \
+            hipLaunchKernelGGL((ctc_char_grad_kernel<__half, NI>), dim3(sg), dim3(256), 0, s, SP_CHAR_ARGS, (__half*)grad,   \
+                               loss, d.perm);                                                                                \
+        else                                                                                                                 \
+            hipLaunchKernelGGL((ctc_char_grad_kernel<float, NI>), dim3(sg), dim3(256), 0, s, SP_CHAR_ARGS, (float*)grad,     \
+                               loss, d.perm);                                                                                \
+    } while (0)
+#define SP_CHAR_ARGS stride_t, stride_b, labels, label_stride, input_lengths, label_lengths, T, B, V, blank, max_label_len,  \
+                     d.RW, d.SP, ws + d.off_rows, al, be, auxp, dbln2, nll, grad_scale
+            if (small) {
+#define DENSE true
+                if (S <= 128) SP_SPARSE(2, 2);
+                else if (S <= 256) SP_SPARSE(4, 2);
+                else if (S <= 512) SP_CHAR(8);
+                else SP_CHAR(16);
+#undef DENSE
+            } else {
+#define DENSE false
+                if (S <= 128) SP_SPARSE(2, 2);   // measured at 32 x 751 x 1000: 19.9 / 18.5 / 21.4 us at 1 / 2 / 4 frames per wave
+                else if (S <= 256) SP_SPARSE(4, 2);
+                else SP_SPARSE(8, 1);   // registers: one frame per wave at eight states per lane (47 against 60 us)
+#undef DENSE
+            }
 #undef SP_SPARSE
+#undef SP_CHAR
+#undef SP_CHAR_ARGS
 #undef SP_GRAD_ARGS
         } else {
 #define SP_GRAD_ARGS logits, stride_t, stride_b, labels, label_stride, input_lengths, label_lengths, T, B, V, blank,   \
-                     max_label_len, d.RW, d.SP, d.modeB, ws + d.off_lse, ws + d.off_rows, dbl,                      \
-                     dbl + (size_t)B * T * d.SP, auxp, dbl + (size_t)2 * B * T * d.SP, nll, grad_scale
+                     max_label_len, d.RW, d.SP, d.modeB, ws + d.off_lse, ws + d.off_rows, dbl, dblb, auxp, dbln2, nll, grad_scale
             if (grad && grad_dtype == SP_BF16)
                 hipLaunchKernelGGL((ctc_grad_kernel<__hip_bfloat16>), dim3(gb), dim3(256), lds, s, SP_GRAD_ARGS,
                                    T > 0 ? (__hip_bfloat16*)grad : nullptr, loss, d.perm);

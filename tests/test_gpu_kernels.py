@@ -958,6 +958,41 @@ def test_ctc_production_shape_sentencepiece_vocab(cuda):
     assert float(loss) == pytest.approx(float((nll.cpu().double() / ll.double()).mean()), rel=1e-6)
 
 
+@pytest.mark.parametrize("cfg", [(1501, 8, 29, 450), (700, 3, 29, 300), (1100, 5, 40, 500), (1501, 3, 29, 600)])
+def test_ctc_long_form_character_vocab(cuda, cfg):
+    """configs[3] with the reference's characters (text.py:1-12): T' = 1501 frames, up to 450 labels -> 901 lattice
+    states and the fused gradient kernel; further lattice sizes on either side of 1024 states (up to there one wave
+    with sixteen states per lane, above four waves with eight), ragged input lengths.  nll AND gradient against torch's CPU CTC in float64
+    (and float32) on a 2-utterance slice; zero row sums and zero rows beyond each length on the whole batch."""
+    from speech_amd import ops
+    T, B, V, L = cfg
+    g = torch.Generator().manual_seed(T + L)
+    logits = torch.randn(T, B, V, generator=g) * 3
+    labels = torch.randint(1, V, (B, L), generator=g)
+    labels[:, 1::9] = labels[:, 0::9][:, : labels[:, 1::9].shape[1]]           # adjacent repeats
+    ll = torch.randint(L // 2, L + 1, (B,), generator=g).int()
+    ll[0] = L
+    il = torch.full((B,), T, dtype=torch.int32)
+    il[-1] = T - 37                                                             # ragged
+    loss, nll, grad = ops.ctc_fwd_bwd(logits.to(cuda), labels.to(cuda), il.to(cuda), ll.to(cuda), time_major=True,
+                                      max_label_len=L)
+    assert torch.isfinite(nll).all()
+    assert float(grad.sum(2).abs().max()) <= 1e-5
+    assert float(grad[T - 37:, -1].abs().max()) == 0.0
+    sl = [0, B - 1]
+    rl, rnll, rg32 = octc.ctc_torch(logits[:, sl], labels[sl], il[sl], ll[sl])
+    _, rnll64, rg64 = octc.ctc_torch(logits[:, sl], labels[sl], il[sl], ll[sl], dtype=torch.float64)
+    assert np.allclose(nll[sl].cpu().numpy(), rnll64.numpy(), rtol=2e-6)
+    scale = np.array([B / len(sl)], dtype=np.float64)
+    got = grad[:, sl].cpu().double().numpy() * scale
+    g64 = rg64.numpy()
+    gmax = np.abs(g64).max()
+    assert np.abs(got - g64).max() <= 1e-4 * gmax
+    ref32_err = np.abs(rg32.numpy() - g64).max()
+    assert np.abs(got - rg32.numpy()).max() <= 1e-4 * gmax + 2 * ref32_err
+    assert float(loss) == pytest.approx(float((nll.cpu().double() / ll.double()).mean()), rel=1e-6)
+
+
 def test_mel_log_flag(cuda):
     """flags bit 0: natural log of (mel + 1e-6), the optional log stage north_star names (off by default: the
     reference feeds magnitudes).  Against log(oracle + 1e-6); padding frames hold log(1e-6)."""

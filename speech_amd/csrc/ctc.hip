@@ -90,7 +90,9 @@ constexpr int kSplitMaxS = 512;        // ... and up to this many have a sparse-
 // all of the row's sectors a fraction each and the recursion paid 35 us of 141 for it); 64 consecutive states are
 // then whole 64-byte pieces of NS / 4 planes, so the consumers' reads stay coalesced.
 __device__ __forceinline__ int spill_col(int p, int perm) {   // perm = log2(states per lane) of the packed producer, or 0
-    return perm ? ((p & ((1 << perm) - 4)) << 6) + ((p >> perm) << 2) + (p & 3) : p;
+    // (a producer of several waves would put wave w's block of 64 << perm states behind wave w - 1's)
+    const int q = p & ((64 << perm) - 1);
+    return perm ? (p - q) + ((q & ((1 << perm) - 4)) << 6) + ((q >> perm) << 2) + (q & 3) : p;
 }
 __device__ __forceinline__ uint32_t lat_pack(double x) {   // one instruction on the recursion wave (v_alignbit_b32)
     return __builtin_amdgcn_alignbit((uint32_t)__double2hiint(x), (uint32_t)__double2loint(x), 31);
@@ -110,6 +112,7 @@ struct CtcDims {
     int SP;    // padded lattice row (multiple of 8)
     int perm;  // != 0: PACKED rows in the store order of the kernel with 2^perm states per lane (spill_col); 0: f64, in state order
     int modeB; // 1: rows indexed by class, 0: by label position
+    int small, split_ok;   // route (see ctc_dims)
     size_t off_lse, off_rows, total_floats;  // float offsets
     size_t off_dbl;  // float offset of alpha[B][T][SP] (f64 or packed words), 16-byte aligned like the next two
     size_t off_beta, off_nll2;   // beta_rev[B][T][SP], nll2[B] (f64)
@@ -123,10 +126,13 @@ static CtcDims ctc_dims(int T, int B, int V, int Lmax) {
     d.modeB = V <= Lmax + 1;
     d.RW = (int)align_up((size_t)(d.modeB ? V : Lmax + 1), 4);
     const int S = 2 * Lmax + 1;
-    d.perm = S > kSingleWaveMaxS ? 0 : S > 512 ? 4 : S > 256 ? 3 : 0;   // measured: no gain at four states per lane
+    // 256 < S <= 1024: packed rows of the single-wave kernel with eight / sixteen states per lane
+    d.small = d.modeB && V <= 64;
+    d.split_ok = !d.small && S <= kSplitMaxS && 4 * B <= kCUs;
+    d.perm = S > kSingleWaveMaxS || S <= 256 ? 0 : S <= 512 ? 3 : 4;
     // permuted rows and the lattices of two states per lane: every lane has its columns (pitch 64 x states per lane),
     // so the recursion wave's row pointer is one scalar walked by a scalar stride
-    d.SP = d.perm ? 64 << d.perm : S <= 128 ? 128 : (int)align_up((size_t)S, 8);
+    d.SP = d.perm ? (S <= 512 ? 512 : 1024) : S <= 128 ? 128 : (int)align_up((size_t)S, 8);
     size_t o = 0;
     d.off_lse = o; o += align_up((size_t)B * T, 4);
     d.off_rows = o; o += (size_t)B * T * d.RW;
@@ -913,6 +919,9 @@ __global__ __launch_bounds__(kLat1Threads) void ctc_lattice1_kernel(
     };
     auto spill = [&]() {   // one vector-memory op per lane and frame (NS == 2), NS / 4 of them packed
         using u4 = __attribute__((ext_vector_type(4))) unsigned;
+#ifdef SP_LAT1_NOSTORE   // lab: timing only
+        if (T >= 0) return;
+#endif
         if constexpr (kPack) {
 #pragma unroll
             for (int j = 0; j < NS; j += 4) {
@@ -1367,7 +1376,7 @@ __global__ __launch_bounds__(256) void ctc_sparse_kernel(
 // requested one half-frame ahead of its arithmetic (registers for one frame in flight, four waves per SIMD).  The
 // lanes take the states in the producer's store order: every alpha load of the wave is 256 contiguous bytes.
 constexpr int kCharFrames = 8;
-template <typename G, int NI>
+template <typename G, int NI, int PS>   // NI states per lane here, PS per lane of the producer (NI / PS recursion waves)
 __global__ __launch_bounds__(256, NI == 16 ? 3 : 4) void ctc_char_grad_kernel(
     int64_t st, int64_t sb, const int64_t* __restrict__ labels, int label_stride,
     const int32_t* __restrict__ in_len, const int32_t* __restrict__ lab_len, int T, int B, int V, int blank,
@@ -1375,7 +1384,7 @@ __global__ __launch_bounds__(256, NI == 16 ? 3 : 4) void ctc_char_grad_kernel(
     const uint32_t* __restrict__ beta_rev, const double* __restrict__ aux, const double* __restrict__ nll2d,
     const float* __restrict__ nll, float grad_scale, G* __restrict__ grad, float* __restrict__ loss, int perm) {
     __shared__ float s_acc[4][128];   // per wave: the classes' occupancies | a dummy slot per lane
-    constexpr int NH = NI / 2, Q = NI / 4;
+    constexpr int NH = NI / 2, Q = PS / 4;
     const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);   // uniform: row pointers stay scalar
     const int wpb = blockDim.x >> 6;
     if (blockIdx.x == 0 && wave == 0 && loss) {
@@ -1389,8 +1398,12 @@ __global__ __launch_bounds__(256, NI == 16 ? 3 : 4) void ctc_char_grad_kernel(
     const int groups = (T + kCharFrames - 1) / kCharFrames;
     const int64_t nitems = (int64_t)B * groups;
     const int aux_stride = kAuxDummy + T / kRescale + 2;
-    // load i of the wave: plane i % Q of the producer lanes 16 (i / Q) .. + 15, four consecutive states per producer lane
-    auto state_of = [&](int i) { return (((i / Q) * 16 + (lane >> 2)) * NI) + (i % Q) * 4 + (lane & 3); };
+    // load i of the wave: of producer wave i / PS, plane (i % PS) % Q of its lanes 16 ((i % PS) / Q) .. + 15, four
+    // consecutive states per producer lane: 256 contiguous bytes at word woff(i) + lane of the row
+    auto state_of = [&](int i) {
+        return (i / PS) * 64 * PS + ((((i % PS) / Q) * 16 + (lane >> 2)) * PS) + ((i % PS) % Q) * 4 + (lane & 3);
+    };
+    auto woff = [](int i) { return (i / PS) * 64 * PS + ((i % PS) % Q) * 256 + ((i % PS) / Q) * 64; };
     const int lc = min(lane, V - 1);
     for (int64_t it = (int64_t)blockIdx.x * wpb + wave; it < nitems; it += (int64_t)gridDim.x * wpb) {
         const int b = (int)(it / groups), t0 = (int)(it % groups) * kCharFrames;
@@ -1429,7 +1442,7 @@ __global__ __launch_bounds__(256, NI == 16 ? 3 : 4) void ctc_char_grad_kernel(
 #pragma unroll
                 for (int k = 0; k < NH; ++k) {
                     const int i = h * NH + k;
-                    a[k] = ar[ulane + (uint32_t)((i % Q) * 256 + (i / Q) * 64)];
+                    a[k] = ar[ulane + (uint32_t)woff(i)];
                     bb[k] = br[boff[i]];
                 }
             };
@@ -1584,8 +1597,8 @@ extern "C" int sp_ctc_fwd_bwd(const float* logits, int64_t stride_t, int64_t str
     const bool have_grad = grad && T > 0;
     // Small vocabularies with class-indexed rows (the reference's 28 characters + blank): the sparse-half kernel writes
     // whole gradient rows (kDense), at any batch size and any single-wave lattice; no dense half, no fused kernel.
-    const bool small = have_grad && d.modeB && V <= 64 && S <= kSingleWaveMaxS;
-    const bool split = have_grad && !small && S <= kSplitMaxS && 4 * B <= kCUs;
+    const bool small = have_grad && d.small && S <= kSingleWaveMaxS;
+    const bool split = have_grad && d.split_ok;
     // How many: the dense half should END with the lattice, not race it -- with all free CUs streaming, the recursion
     // lost 10 % (32 x 751: 41.8 us with 96 dense workgroups, 43.8 with 160, 45.5 with 192) although no streaming wave
     // shares its CUs.  A CU streams ~32 GB/s of rows that the Infinity Cache still holds and ~22 GB/s from HBM; the
@@ -1643,20 +1656,20 @@ extern "C" int sp_ctc_fwd_bwd(const float* logits, int64_t stride_t, int64_t str
             hipLaunchKernelGGL((ctc_sparse_kernel<float, NI, R, DENSE>), dim3(sg), dim3(256), sl, s, SP_GRAD_ARGS,           \
                                (float*)grad, loss, d.perm);                                                                  \
     } while (0)
-#define SP_CHAR(NI)                                                                                                          \
+#define SP_CHAR(NI, PS)                                                                                                      \
     do {                                                                                                                     \
         const int64_t items = (int64_t)B * ((T + kCharFrames - 1) / kCharFrames);                                            \
         const int sg = (int)std::min<int64_t>((items + 3) / 4, 16384);                                                       \
         const uint32_t* al = reinterpret_cast<const uint32_t*>(dbl);                                                         \
         const uint32_t* be = reinterpret_cast<const uint32_t*>(dblb);                                                        \
         if (grad_dtype == SP_BF16)                                                                                           \
-            hipLaunchKernelGGL((ctc_char_grad_kernel<__hip_bfloat16, NI>), dim3(sg), dim3(256), 0, s, SP_CHAR_ARGS,          \
+            hipLaunchKernelGGL((ctc_char_grad_kernel<__hip_bfloat16, NI, PS>), dim3(sg), dim3(256), 0, s, SP_CHAR_ARGS,          \
                                (__hip_bfloat16*)grad, loss, d.perm);                                                         \
         else if (grad_dtype == SP_F16)                                                                                       \
-            hipLaunchKernelGGL((ctc_char_grad_kernel<__half, NI>), dim3(sg), dim3(256), 0, s, SP_CHAR_ARGS, (__half*)grad,   \
+            hipLaunchKernelGGL((ctc_char_grad_kernel<__half, NI, PS>), dim3(sg), dim3(256), 0, s, SP_CHAR_ARGS, (__half*)grad,   \
                                loss, d.perm);                                                                                \
         else                                                                                                                 \
-            hipLaunchKernelGGL((ctc_char_grad_kernel<float, NI>), dim3(sg), dim3(256), 0, s, SP_CHAR_ARGS, (float*)grad,     \
+            hipLaunchKernelGGL((ctc_char_grad_kernel<float, NI, PS>), dim3(sg), dim3(256), 0, s, SP_CHAR_ARGS, (float*)grad,     \
                                loss, d.perm);                                                                                \
     } while (0)
 #define SP_CHAR_ARGS stride_t, stride_b, labels, label_stride, input_lengths, label_lengths, T, B, V, blank, max_label_len,  \
@@ -1665,8 +1678,8 @@ extern "C" int sp_ctc_fwd_bwd(const float* logits, int64_t stride_t, int64_t str
 #define DENSE true
                 if (S <= 128) SP_SPARSE(2, 2);
                 else if (S <= 256) SP_SPARSE(4, 2);
-                else if (S <= 512) SP_CHAR(8);
-                else SP_CHAR(16);
+                else if (S <= 512) SP_CHAR(8, 8);
+                else SP_CHAR(16, 16);
 #undef DENSE
             } else {
 #define DENSE false

@@ -77,6 +77,7 @@ constexpr int kAuxDummy = 512;   // doubles of the single-wave kernel's dummy sp
 constexpr int kLat1Threads = 512;      // workgroup of ctc_lattice1_kernel: with kLat1DynLds one workgroup owns a CU
 constexpr int kLat1DynLds = 20 * 1024;  // unused dynamic LDS on top of the 64 KB of emissions: a second workgroup does not fit
 constexpr int kSingleWaveMaxS = 1024;  // lattices up to this many states run on ctc_lattice1_kernel
+constexpr bool kPackAll = true;        // every single-wave lattice spills packed rows (lat_pack), not only eight / sixteen states per lane
 constexpr int kSplitMaxS = 512;        // ... and up to this many have a sparse-half kernel (dense half beside the lattice)
 
 // Lattices of eight and sixteen states per lane (256 < S <= 1024) are spilled PACKED: exponent and the upper 21 bits
@@ -92,7 +93,7 @@ constexpr int kSplitMaxS = 512;        // ... and up to this many have a sparse-
 __device__ __forceinline__ int spill_col(int p, int perm) {   // perm = log2(states per lane) of the packed producer, or 0
     // (a producer of several waves would put wave w's block of 64 << perm states behind wave w - 1's)
     const int q = p & ((64 << perm) - 1);
-    return perm ? (p - q) + ((q & ((1 << perm) - 4)) << 6) + ((q >> perm) << 2) + (q & 3) : p;
+    return perm > 2 ? (p - q) + ((q & ((1 << perm) - 4)) << 6) + ((q >> perm) << 2) + (q & 3) : p;   // up to four states per lane: state order
 }
 __device__ __forceinline__ uint32_t lat_pack(double x) {   // one instruction on the recursion wave (v_alignbit_b32)
     return __builtin_amdgcn_alignbit((uint32_t)__double2hiint(x), (uint32_t)__double2loint(x), 31);
@@ -129,10 +130,10 @@ static CtcDims ctc_dims(int T, int B, int V, int Lmax) {
     // 256 < S <= 1024: packed rows of the single-wave kernel with eight / sixteen states per lane
     d.small = d.modeB && V <= 64;
     d.split_ok = !d.small && S <= kSplitMaxS && 4 * B <= kCUs;
-    d.perm = S > kSingleWaveMaxS || S <= 256 ? 0 : S <= 512 ? 3 : 4;
+    d.perm = S > kSingleWaveMaxS ? 0 : S <= 256 ? (kPackAll ? (S <= 128 ? 1 : 2) : 0) : S <= 512 ? 3 : 4;
     // permuted rows and the lattices of two states per lane: every lane has its columns (pitch 64 x states per lane),
     // so the recursion wave's row pointer is one scalar walked by a scalar stride
-    d.SP = d.perm ? (S <= 512 ? 512 : 1024) : S <= 128 ? 128 : (int)align_up((size_t)S, 8);
+    d.SP = d.perm ? 64 << d.perm : S <= 128 ? 128 : (int)align_up((size_t)S, 8);
     size_t o = 0;
     d.off_lse = o; o += align_up((size_t)B * T, 4);
     d.off_rows = o; o += (size_t)B * T * d.RW;
@@ -872,7 +873,7 @@ __global__ __launch_bounds__(kLat1Threads) void ctc_lattice1_kernel(
     // ---------------------------------------------------------------------- recursion wave
     // the serial chain outranks the streaming waves of the dense half that may share its SIMD
     __builtin_amdgcn_s_setprio(3);
-    constexpr bool kPack = NS >= 8;   // four-byte states (lat_pack)
+    constexpr bool kPack = NS >= 8 || kPackAll;   // four-byte states (lat_pack)
     constexpr int kEsz = kPack ? 4 : 8;
     char* outb = reinterpret_cast<char*>(dir ? beta_rev : alpha) + (int64_t)b * T * SP * kEsz;
     double* out = reinterpret_cast<double*>(outb);
@@ -889,7 +890,7 @@ __global__ __launch_bounds__(kLat1Threads) void ctc_lattice1_kernel(
     const int aux_stride = kAuxDummy + T / kRescale + 2;
     double* aux_b = aux + ((int64_t)dir * B + b) * aux_stride;
     double* ecum = aux_b + kAuxDummy;
-    constexpr bool kAllLanes = NS != 4;   // the row pitch is 64 NS (ctc_dims): every lane has its columns
+    constexpr bool kAllLanes = NS != 4 || kPack;   // the row pitch is 64 NS (ctc_dims): every lane has its columns
     const bool spill_ok = kAllLanes || lane * NS < SP;
     // row pointer of the frame being written: walks forward (alpha) or backward (beta) by one row
     double* orow = spill_ok ? out + (int64_t)(dir ? Tb - 1 : 0) * SP + lane * NS : aux_b + lane * NS;   // NS == 4 only
@@ -901,7 +902,7 @@ __global__ __launch_bounds__(kLat1Threads) void ctc_lattice1_kernel(
     const int ostep_b = (dir ? -SP : SP) * kEsz;
     // lanes whose states all lie beyond the utterance's lattice store nothing: their offset is out of the descriptor's
     // range and the hardware drops the lanes (the consumers read columns < S only)
-    const int loff = (kPack && lane * NS >= S) ? 0x7F000000 : lane * 16;
+    const int loff = (kPack && lane * NS >= S) ? 0x7F000000 : lane * (kPack && NS == 2 ? 8 : 16);
     auto step = [&](const double (&yq)[NS]) {
         const double p1 = lane_shr1(a[NS - 1]);
         double n_[NS];
@@ -922,7 +923,11 @@ __global__ __launch_bounds__(kLat1Threads) void ctc_lattice1_kernel(
 #ifdef SP_LAT1_NOSTORE   // lab: timing only
         if (T >= 0) return;
 #endif
-        if constexpr (kPack) {
+        if constexpr (kPack && NS == 2) {
+            using u2 = __attribute__((ext_vector_type(2))) unsigned;
+            const u2 v = {lat_pack(a[0]), lat_pack(a[1])};
+            __builtin_amdgcn_raw_buffer_store_b64(v, orsrc, loff, osoff, 0);
+        } else if constexpr (kPack) {
 #pragma unroll
             for (int j = 0; j < NS; j += 4) {
                 const u4 v = {lat_pack(a[j]), lat_pack(a[j + 1]), lat_pack(a[j + 2]), lat_pack(a[j + 3])};
@@ -1146,7 +1151,7 @@ __global__ __launch_bounds__(256) void ctc_sparse_kernel(
     const void* __restrict__ beta_rev, const double* __restrict__ aux, const double* __restrict__ nll2d,
     const float* __restrict__ nll, float grad_scale, G* __restrict__ grad, float* __restrict__ loss, int perm) {
     extern __shared__ __attribute__((aligned(16))) float s_dyn[];  // per wave: first[V] (int) | acc[kR][AL]; kDense: acc[kR][V]
-    constexpr bool kPack = NI >= 8;
+    constexpr bool kPack = NI >= 8 || kPackAll;
     using LT = typename std::conditional<kPack, uint32_t, double>::type;
     const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);   // uniform: row pointers stay scalar
     const int wpb = blockDim.x >> 6;
@@ -1173,7 +1178,7 @@ __global__ __launch_bounds__(256) void ctc_sparse_kernel(
     // state of (lane, i).  Packed rows are [NI / 4 planes][64 producer lanes][4]: load i of the wave takes plane
     // i % (NI / 4) of the producer lanes 16 (i / (NI / 4)) .. + 15, four consecutive states per producer lane
     auto state_of = [&](int i) {
-        if constexpr (kPack) return (((i / (NI / 4)) * 16 + (lane >> 2)) * NI) + (i % (NI / 4)) * 4 + (lane & 3);
+        if constexpr (NI >= 8) return (((i / (NI / 4)) * 16 + (lane >> 2)) * NI) + (i % (NI / 4)) * 4 + (lane & 3);
         else return lane + 64 * i;
     };
     for (int64_t it = (int64_t)blockIdx.x * wpb + wave; it < nitems; it += (int64_t)gridDim.x * wpb) {

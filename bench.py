@@ -40,9 +40,11 @@ PMC_TRAFFIC_BYTES = {
     ("gemm_nt(forward projection U = LN(x) W)", "bf16", 32, 15.0): 2 * 127609.6 * 1024 + 144248.8 * 1024,
     ("gemm_nt(data gradient gX = gU W^T)", "bf16", 32, 15.0): 2 * 123362.9 * 1024 + 48064.0 * 1024,
     ("gemm_tn(weight gradient dW = LN(x)^T gU, split-K)", "bf16", 32, 15.0): 2 * 137164.3 * 1024 + 61440.5 * 1024,
-    # round 2 (profiles/r02_pmc_traffic.md; kernels unchanged since)
+    # round 2 (profiles/r02_pmc_traffic.md; kernel unchanged since)
     ("melspec_kernel", "bf16", 32, 15.0): 2 * 16019.0 * 1024 + 18300.0 * 1024,
-    ("ctc_fwd_bwd(3 kernels)", "bf16", 32, 15.0): (2 * 47032.0 + 2 * 52370.0 + 2 * 21862.0 + 4882.0 + 142004.0 + 29987.0) * 1024,
+    # round 3 (profiles/r03_pmc_traffic.md): rows + lattice / dense half (16-byte loads: x2) + sparse half (4-byte loads: raw
+    # counter, a lower bound), packed lattice rows
+    ("ctc_fwd_bwd(3 kernels)", "bf16", 32, 15.0): (2 * 48157.0 + 2 * 52896.0 + 13632.0 + 4976.0 + 112238.0 + 29633.0) * 1024,
 }
 MFMA_BF16_PEAK_TF = 2500.0  # dense bf16
 

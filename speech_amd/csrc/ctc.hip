@@ -23,7 +23,10 @@
 //                  frames ahead (issue loads early, write to LDS late).  beta is the same
 //                  recursion on the reversed label sequence over reversed time, so there is one
 //                  code path.  Lattice rows are spilled to the workspace in coalesced rows.
-//   K3 gradient.   Single-wave lattices (S <= 512) split it in two.  The DENSE half, softmax(z) * scale over
+//   K3 gradient.   Vocabularies of <= 64 classes with class-indexed rows (the reference's 28 characters + blank), lattices
+//                  up to 1024 states: ctc_char_grad writes whole gradient rows after the lattice (p - occupancy for
+//                  every class, 32-bit posterior arithmetic on the packed lattice words, no dense half, the logits
+//                  are not read again).  Otherwise single-wave lattices (S <= 512) split it in two.  The DENSE half, softmax(z) * scale over
 //                  the whole vocabulary, needs K1's log-sum-exp only: it rides in K2's launch, in workgroups
 //                  behind the 2B lattice workgroups on the CUs the lattice leaves idle (one workgroup per CU,
 //                  so no streaming wave shares a lattice CU).  The SPARSE half (ctc_sparse) runs after it:
@@ -32,19 +35,20 @@
 //                  Larger lattices keep the fused ctc_grad (whole chip, one wave per (t,b) row:
 //                  occupancies per class in LDS, grad = (softmax - occ) * scale).
 //
-// Workspace: lse2[B*T] | rows[B][T][RW] (f32), then f64 alpha[B][T][SP] | beta_rev[B][T][SP] | nll2[B]
-// | aux.  True alpha_t(s) = alpha[b][t][s] * 2^E_t.  SP = 2*Lmax+1 rounded up to 8 > S (512 and in spill_col order for
-// the lattices of 257..512 states): the multi-wave
-// kernel keeps E_t in slot SP-1 of the row; the single-wave kernel writes E once per 8-frame block
-// into its aux block (and parks the stores of lanes beyond SP on a dummy row there).
+// Workspace: lse2[B*T] | rows[B][T][RW] (f32), then alpha[B][T][SP] | beta_rev[B][T][SP] | nll2[B] (f64)
+// | aux.  True alpha_t(s) = alpha[b][t][s] * 2^E_t.  Single-wave lattices (S <= 1024: 2, 4, 8 or 16 states per lane,
+// SP = 64 x states per lane) spill PACKED rows, four bytes a state (lat_pack / lat_unpack, spill_col order) and write
+// E once per 8-frame block into their aux block; the multi-wave kernel (S > 1024) spills f64 rows of 2*Lmax+1 rounded
+// up to 8 > S slots and keeps E_t in slot SP-1 of the row.
 //
 // Precision: log alpha/beta reach thousands of log2 units, where one f32 ulp is ~2e-4: a plain f32
 // log-space recursion (torch's included) random-walks to ~3e-4 relative error in the posteriors.
 // Scaled f64 probabilities carry 53 bits through every add; the only f32 roundings are the
-// emission exp2 (1 ulp) and K1's log-sum-exp.  The lattice is spilled as f64: for tightly
+// emission exp2 (1 ulp) and K1's log-sum-exp.  The spilled lattice keeps f64's EXPONENT (for tightly
 // constrained alignments the states that carry the posterior sit hundreds of binary orders below
-// the row maximum (f64 reaches 2^-1022 below it; anything smaller is a posterior of zero).  K3
-// multiplies alpha*beta in f64 and applies 2^(E_a + E_b - log2 y - log2 P) by ldexp.
+// the row maximum: f64 reaches 2^-1022 below it; anything smaller is a posterior of zero) and, packed,
+// 21 bits of mantissa (2.4e-7 relative per factor, unbiased; the likelihood itself is summed from the
+// f64 registers).  K3 multiplies the mantissas and applies 2^(e_a + e_b + E_a + E_b - log2 y - log2 P) by ldexp.
 #include <algorithm>
 #include <atomic>
 #include <type_traits>

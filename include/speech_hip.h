@@ -89,9 +89,12 @@ int sp_melspec_fwd(const void* wav, const int64_t* wav_offsets, int B, int T_max
  * test_ctc_sharp_logits_range; a randomly initialised model sits at log2 V, a trained one below 3); scores that are
  * sharper AND wrong for tens of frames on end can push the states that carry the posterior out of f64's range below
  * the row maximum: the result then degrades (percent-level error, finally +inf) instead of staying exact.
+ * Lattices of up to 1024 states are spilled to the workspace as packed four-byte states (f64's exponent, 21 mantissa
+ * bits): posteriors carry 2.4e-7 of relative rounding, the likelihood none (csrc/ctc.hip).
  * Three launches on `stream` and nothing else (no second stream, no events, no allocation): the dense half of the
  * gradient shares the lattice's launch, see csrc/ctc.hip.  grad rows are written twice (dense half, then the label
- * classes' entries): read grad only after the call's work on `stream` is complete.
+ * classes' entries) -- once, by the third launch, for vocabularies of <= 64 classes (the reference's characters):
+ * read grad only after the call's work on `stream` is complete.
  * --------------------------------------------------------------------------------------- */
 size_t sp_ctc_workspace_bytes(int T, int B, int V, int max_label_len);
 int sp_ctc_fwd_bwd(const float* logits, int64_t stride_t, int64_t stride_b, const int64_t* labels,

@@ -993,6 +993,42 @@ def test_ctc_long_form_character_vocab(cuda, cfg):
     assert float(loss) == pytest.approx(float((nll.cpu().double() / ll.double()).mean()), rel=1e-6)
 
 
+@pytest.mark.parametrize("cfg", [(300, 70, 29, 120), (64, 5, 29, 10), (200, 130, 40, 60), (520, 9, 64, 257)])
+def test_ctc_character_vocab_route_batches_and_dtypes(cuda, cfg):
+    """The whole-row gradient route of vocabularies of <= 64 classes (ctc_sparse_kernel<.., dense> up to 256 lattice
+    states, ctc_char_grad_kernel above) at batches beyond 64 (no dense half exists on this route, so no batch limit),
+    every lattice size class, a label that names the BLANK class, ragged lengths; f32 gradient against torch's f64 CPU
+    run on a 2-utterance slice, bf16 / f16 gradients = the f32 gradient rounded once."""
+    from speech_amd import ops
+    T, B, V, L = cfg
+    g = torch.Generator().manual_seed(T * 7 + B)
+    logits = torch.randn(T, B, V, generator=g) * 2
+    labels = torch.randint(1, V, (B, L), generator=g)
+    if V <= L + 1:                                                              # the class-indexed route only (the
+        labels[0, L // 2] = 0                                                   # position-indexed one never supported it):
+    ll = torch.randint(max(L // 2, 1), L + 1, (B,), generator=g).int()         # a label equal to the blank index
+    ll[0] = L
+    il = torch.full((B,), T, dtype=torch.int32)
+    il[-1] = T - 11
+    dl, dlab, dil, dll = logits.to(cuda), labels.to(cuda), il.to(cuda), ll.to(cuda)
+    loss, nll, grad = ops.ctc_fwd_bwd(dl, dlab, dil, dll, time_major=True, max_label_len=L)
+    assert torch.isfinite(nll).all()
+    assert float(grad[T - 11:, -1].abs().max()) == 0.0
+    sl = [0, B - 1]
+    _, rnll64, rg64 = octc.ctc_torch(logits[:, sl], labels[sl], il[sl], ll[sl], dtype=torch.float64)
+    assert np.allclose(nll[sl].cpu().numpy(), rnll64.numpy(), rtol=2e-6)
+    got = grad[:, sl].cpu().double().numpy() * (B / len(sl))
+    assert np.abs(got - rg64.numpy()).max() <= 1e-4 * np.abs(rg64.numpy()).max()
+    # 16-bit gradients are ONE rounding of (p - occupancy) * scale (the compiler fuses the scaling into the conversion),
+    # so they are within half a 16-bit ulp of the f32 gradient and equal to its rounding except where that sits on a tie
+    _, _, g32 = ops.ctc_fwd_bwd(dl, dlab, dil, dll, time_major=True, max_label_len=L, grad_scale=32.0)
+    for dt, half_ulp, tiny in ((torch.bfloat16, 2.0 ** -8, 2.0 ** -134), (torch.float16, 2.0 ** -11, 2.0 ** -25)):
+        _, _, g16 = ops.ctc_fwd_bwd(dl, dlab, dil, dll, time_major=True, max_label_len=L, grad_scale=32.0, grad_dtype=dt)
+        assert g16.dtype == dt
+        assert bool(((g16.float() - g32).abs() <= g32.abs() * half_ulp * 1.0001 + tiny).all())
+        assert float((g16 != g32.to(dt)).float().mean()) < 1e-3
+
+
 def test_mel_log_flag(cuda):
     """flags bit 0: natural log of (mel + 1e-6), the optional log stage north_star names (off by default: the
     reference feeds magnitudes).  Against log(oracle + 1e-6); padding frames hold log(1e-6)."""

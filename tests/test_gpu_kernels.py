@@ -1029,6 +1029,43 @@ def test_ctc_character_vocab_route_batches_and_dtypes(cuda, cfg):
         assert float((g16 != g32.to(dt)).float().mean()) < 1e-3
 
 
+def test_ctc_random_shapes_against_torch_f64(cuda):
+    """Differential sweep over the routes of sp_ctc_fwd_bwd: 80 seeded random shapes (T <= 90, B <= 7, V from 2 to 80,
+    label lengths up to 300 where T allows: class-indexed and position-indexed rows, every lattice size class up to
+    sixteen states per lane, ragged input lengths, empty labels, infeasible utterances); nll and gradient against
+    torch's float64 CPU CTC (zero_infinity semantics checked on the feasible utterances only)."""
+    from speech_amd import ops
+    rng = np.random.RandomState(20251)
+    ngrad = ninf = 0
+    for case in range(80):
+        B = int(rng.randint(1, 8))
+        V = int(rng.choice([2, 3, 5, 17, 29, 33, 64, 65, 80]))
+        big = case % 4 == 0
+        T = int(rng.randint(200, 640)) if big else int(rng.randint(1, 90))
+        L = int(rng.randint(1, min(300, T))) if big else int(rng.randint(0, max(1, T // 2) + 1))
+        g = torch.Generator().manual_seed(1000 + case)
+        logits = torch.randn(T, B, V, generator=g) * float(rng.choice([0.5, 2.0, 5.0]))
+        labels = torch.randint(1, V, (B, max(L, 1)), generator=g)
+        ll = torch.randint(0, L + 1, (B,), generator=g).int()
+        ll[0] = L
+        il = torch.randint(max(T // 2, 1), T + 1, (B,), generator=g).int()
+        il[0] = T
+        loss, nll, grad = ops.ctc_fwd_bwd(logits.to(cuda), labels.to(cuda), il.to(cuda), ll.to(cuda), time_major=True,
+                                          max_label_len=max(L, 1))
+        _, rnll, rg = octc.ctc_torch(logits, labels, il, ll, dtype=torch.float64)
+        rn = rnll.numpy()
+        feas = np.isfinite(rn) & (rn < 1e29)
+        got_n = nll.cpu().numpy()
+        assert np.allclose(got_n[feas], rn[feas], rtol=2e-6, atol=1e-5), (case, T, B, V, L)
+        assert np.all(~np.isfinite(got_n[~feas]) | (got_n[~feas] > 1e29)), (case, T, B, V, L)
+        ninf += int((~feas).sum())
+        if feas.all():
+            ngrad += 1
+            gmax = max(float(np.abs(rg.numpy()).max()), 1e-30)
+            assert float(np.abs(grad.cpu().double().numpy() - rg.numpy()).max()) <= 1e-4 * gmax, (case, T, B, V, L)
+    assert ngrad >= 20 and ninf >= 5, (ngrad, ninf)      # the sweep really holds both kinds
+
+
 def test_mel_log_flag(cuda):
     """flags bit 0: natural log of (mel + 1e-6), the optional log stage north_star names (off by default: the
     reference feeds magnitudes).  Against log(oracle + 1e-6); padding frames hold log(1e-6)."""
